@@ -1,0 +1,120 @@
+"""ctypes loader for libgmrm_hip.so (C ABI: include/gmrm_hip.h)."""
+import ctypes as C
+import os
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+_LIB = None
+
+
+class GmrmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libgmrm_hip error {code}: {msg}")
+        self.code = code
+
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_u8_p = C.POINTER(C.c_uint8)
+
+KMAX = 8
+GMAX = 64
+
+
+class SweepIn(C.Structure):
+    _fields_ = [("G", C.c_int), ("K", C.c_int), ("order", c_int_p), ("sigmag", c_double_p),
+                ("pi_est", c_double_p), ("cva", c_double_p), ("sigmae", C.c_double),
+                ("rng_state", C.c_uint32 * 624), ("rng_index", C.c_int)]
+
+
+class SweepOut(C.Structure):
+    _fields_ = [("cass", c_int_p), ("rng_state", C.c_uint32 * 624), ("rng_index", C.c_int),
+                ("n_updates", C.c_longlong), ("n_batches", C.c_longlong), ("device_ms", C.c_double)]
+
+
+class SamplerOpts(C.Structure):
+    _fields_ = [("seed", C.c_uint32), ("rank", C.c_int), ("nranks", C.c_int), ("shuffle", C.c_int),
+                ("mimic_hydra", C.c_int), ("G", C.c_int), ("K", C.c_int), ("cva", c_double_p),
+                ("group_index", c_int_p)]
+
+
+class HyperC(C.Structure):
+    _fields_ = [("sigmae", C.c_double), ("mu", C.c_double), ("m0_sum", C.c_int),
+                ("sigmag", C.c_double * GMAX), ("pi_est", C.c_double * (GMAX * KMAX)),
+                ("n_updates", C.c_longlong), ("n_batches", C.c_longlong), ("sweep_device_ms", C.c_double)]
+
+
+VP = C.c_void_p
+# name -> (restype, argtypes); every symbol include/gmrm_hip.h declares
+SIGNATURES = {
+    "gmrm_last_error": (C.c_char_p, []),
+    "gmrm_abi_version": (C.c_int, []),
+    "gmrm_device_count": (C.c_int, []),
+    "gmrm_ctx_create": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gmrm_ctx_destroy": (C.c_int, [VP]),
+    "gmrm_ctx_sync": (C.c_int, [VP]),
+    "gmrm_upload_bed": (C.c_int, [VP, c_u8_p, C.c_size_t, C.c_size_t]),
+    "gmrm_download_bed": (C.c_int, [VP, c_u8_p, C.c_size_t, C.c_size_t]),
+    "gmrm_synth_bed": (C.c_int, [VP, C.c_uint64, C.c_double, C.c_double]),
+    "gmrm_upload_trait": (C.c_int, [VP, C.c_int, c_double_p, c_u8_p, C.c_int]),
+    "gmrm_download_eps": (C.c_int, [VP, C.c_int, c_double_p]),
+    "gmrm_upload_eps": (C.c_int, [VP, C.c_int, c_double_p]),
+    "gmrm_marker_stats": (C.c_int, [VP, C.c_int]),
+    "gmrm_get_marker_stats": (C.c_int, [VP, C.c_int, c_double_p, c_double_p]),
+    "gmrm_set_marker_stats": (C.c_int, [VP, C.c_int, c_double_p, c_double_p]),
+    "gmrm_dot": (C.c_int, [VP, C.c_int, C.c_int, C.c_double, C.c_double, c_double_p]),
+    "gmrm_update_eps": (C.c_int, [VP, C.c_int, C.c_int, c_double_p]),
+    "gmrm_offset_eps": (C.c_int, [VP, C.c_int, C.c_double]),
+    "gmrm_sumsqr": (C.c_int, [VP, C.c_int, c_double_p]),
+    "gmrm_eps_sigma": (C.c_int, [VP, C.c_int, c_double_p]),
+    "gmrm_set_groups": (C.c_int, [VP, c_int_p]),
+    "gmrm_sweep_launch": (C.c_int, [VP, C.c_int, C.POINTER(SweepIn)]),
+    "gmrm_sweep_finish": (C.c_int, [VP, C.c_int, C.POINTER(SweepOut)]),
+    "gmrm_get_betas": (C.c_int, [VP, C.c_int, c_double_p]),
+    "gmrm_get_comp": (C.c_int, [VP, C.c_int, c_int_p]),
+    "gmrm_get_acum": (C.c_int, [VP, C.c_int, c_double_p]),
+    "gmrm_set_betas": (C.c_int, [VP, C.c_int, c_double_p]),
+    "gmrm_eps_snapshot": (C.c_int, [VP, C.c_int]),
+    "gmrm_eps_delta_export": (C.c_int, [VP, C.c_int, VP]),
+    "gmrm_eps_delta_import": (C.c_int, [VP, C.c_int, VP]),
+    "gmrm_sampler_create": (C.c_int, [C.POINTER(VP), VP, C.POINTER(SamplerOpts)]),
+    "gmrm_sampler_destroy": (C.c_int, [VP]),
+    "gmrm_sampler_init": (C.c_int, [VP]),
+    "gmrm_sampler_iterate": (C.c_int, [VP, C.c_int]),
+    "gmrm_sampler_draw_mu": (C.c_int, [VP, C.c_int, c_double_p]),
+    "gmrm_sampler_begin_sweep": (C.c_int, [VP, c_double_p]),
+    "gmrm_sampler_end_sweep": (C.c_int, [VP, c_int_p, c_double_p]),
+    "gmrm_sampler_epilogue": (C.c_int, [VP, c_int_p, c_double_p]),
+    "gmrm_sampler_adopt": (C.c_int, [VP, C.c_int, c_double_p, c_double_p, C.c_double]),
+    "gmrm_sampler_get": (C.c_int, [VP, C.c_int, C.POINTER(HyperC)]),
+    "gmrm_sampler_csv_line": (C.c_int, [VP, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+}
+
+
+def library_path() -> Path:
+    return Path(os.environ.get("GMRM_HIP_LIB", HERE / "libgmrm_hip.so"))
+
+
+def load_library():
+    """Load libgmrm_hip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not path.exists():
+        raise ImportError(f"{path} is missing: build it with `python -m gmrm_amd.build` "
+                          "(hipcc --offload-arch=gfx950). gmrm_amd has no CPU fallback.")
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        msg = load_library().gmrm_last_error()
+        raise GmrmError(rc, msg.decode() if msg else "?")
+    return rc

@@ -1,0 +1,490 @@
+// capi.cpp -- context management and the C ABI of libgmrm_hip (include/gmrm_hip.h).
+// Host-side glue only: device buffers, streams, launches.  No CPU compute fallback: every
+// compute entry needs a HIP device and fails with GMRM_ENODEV / GMRM_EHIP otherwise.
+#include "../../include/gmrm_hip.h"
+#include "gm_common.h"
+#include "gm_internal.h"
+#include "gm_host.h"
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace gm {
+
+static thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+static int hip_fail(hipError_t e, const char* what) {
+    return fail(GMRM_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
+
+template <class T> static hipError_t dalloc(T** p, size_t n) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemset(*p, 0, n * sizeof(T));
+}
+
+int ctx_check_t(const gmrm_ctx* c, int t) {
+    if (!c) return fail(GMRM_EINVAL, "null context");
+    if (t < 0 || t >= c->T) return fail(GMRM_EINVAL, "phenotype index out of range");
+    return GMRM_OK;
+}
+
+}  // namespace gm
+
+using namespace gm;
+
+extern "C" {
+
+const char* gmrm_last_error(void) { return g_err.c_str(); }
+int gmrm_abi_version(void) { return 1; }
+int gmrm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int T) {
+    if (!out) return fail(GMRM_EINVAL, "out is null");
+    *out = nullptr;
+    if (N < 2 || M < 0 || Mt < M || S < 0 || S + M > Mt || T < 1 || T > 64)
+        return fail(GMRM_EINVAL, "bad dimensions");
+    if (((long long)N + 3) / 4 > (1ll << gm::MAX_LOG2_N) / 4)
+        return fail(GMRM_EINVAL, "N exceeds 2^22 individuals (limit of the exact-summation bins)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(GMRM_ENODEV, "no HIP device visible: libgmrm_hip has no CPU path");
+    if (device < 0 || device >= ndev) return fail(GMRM_EINVAL, "device index out of range");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+
+    gmrm_ctx* c = new gmrm_ctx();
+    c->device = device; c->N = N; c->M = M; c->Mt = Mt; c->S = S; c->T = T;
+    c->mbytes = ((size_t)N + 3) / 4;                          // bayes.cpp:776
+    c->stride = (c->mbytes + 15) / 16 * 16;
+    c->num_cu = prop.multiProcessorCount;
+    // workgroups per chain: all phenotypes sweep concurrently when they fit side by side
+    int maxwg = c->num_cu / T;
+    c->R = maxwg >= 1 ? sweep_pick_R(c->stride, maxwg, &c->W) : -1;
+    c->concurrent = c->R > 0;
+    if (c->R < 0) c->R = sweep_pick_R(c->stride, c->num_cu, &c->W);
+    if (c->R < 0) { delete c; return fail(GMRM_EINVAL, "N too large for the resident-residual sweep kernel"); }
+    c->Wpad = (c->W + 15) / 16 * 16;
+
+    hipError_t e = hipSuccess;
+    const size_t bedbytes = (size_t)(M > 0 ? M : 1) * c->stride;
+    e = hipMalloc(reinterpret_cast<void**>(&c->bed), bedbytes);
+    if (e != hipSuccess) { delete c; return fail(GMRM_ENOMEM, std::string("hipMalloc(bed): ") + hipGetErrorString(e)); }
+    HIPCHK(hipMemset(c->bed, 0, bedbytes));
+    HIPCHK(dalloc(&c->group, (size_t)(M > 0 ? M : 1)));
+    c->tr.resize(T);
+    const size_t n4 = 4 * c->stride, Mm = (size_t)(M > 0 ? M : 1);
+    for (int t = 0; t < T; t++) {
+        Trait& tr = c->tr[t];
+        HIPCHK(dalloc(&tr.eps, n4));
+        HIPCHK(dalloc(&tr.eps_start, n4));
+        HIPCHK(dalloc(&tr.namask2, c->stride));
+        HIPCHK(dalloc(&tr.mave, Mm));
+        HIPCHK(dalloc(&tr.msig, Mm));
+        HIPCHK(dalloc(&tr.betas[0], Mm));
+        HIPCHK(dalloc(&tr.betas[1], Mm));
+        HIPCHK(dalloc(&tr.comp, Mm));
+        HIPCHK(dalloc(&tr.acum, Mm));
+        HIPCHK(dalloc(&tr.order, Mm));
+        HIPCHK(dalloc(&tr.tab, (size_t)GMAX * (1 + 3 * KMAX)));
+        HIPCHK(dalloc(&tr.rng_state, (size_t)624));
+        HIPCHK(dalloc(&tr.rng_index, (size_t)4));
+        HIPCHK(dalloc(&tr.cass, (size_t)GMAX * KMAX));
+        HIPCHK(dalloc(&tr.stats, (size_t)4));
+        HIPCHK(dalloc(&tr.err, (size_t)4));
+        HIPCHK(dalloc(&tr.P, (size_t)SW_VMAX * c->Wpad));
+        HIPCHK(dalloc(&tr.Tt, (size_t)SW_VMAX));
+        HIPCHK(dalloc(&tr.cnt, (size_t)96));
+        HIPCHK(dalloc(&tr.scratch, (size_t)8));
+        HIPCHK(hipStreamCreateWithFlags(&tr.stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&tr.ev0));
+        HIPCHK(hipEventCreate(&tr.ev1));
+    }
+    *out = c;
+    return GMRM_OK;
+}
+
+int gmrm_ctx_destroy(gmrm_ctx* c) {
+    if (!c) return GMRM_OK;
+    hipSetDevice(c->device);
+    for (auto& tr : c->tr) {
+        if (tr.stream) hipStreamSynchronize(tr.stream);
+        hipFree(tr.eps); hipFree(tr.eps_start); hipFree(tr.namask2); hipFree(tr.mave); hipFree(tr.msig);
+        hipFree(tr.betas[0]); hipFree(tr.betas[1]); hipFree(tr.comp); hipFree(tr.acum); hipFree(tr.order);
+        hipFree(tr.tab); hipFree(tr.rng_state); hipFree(tr.rng_index); hipFree(tr.cass); hipFree(tr.stats);
+        hipFree(tr.err); hipFree(tr.P); hipFree(tr.Tt); hipFree(tr.cnt); hipFree(tr.scratch);
+        if (tr.ev0) hipEventDestroy(tr.ev0);
+        if (tr.ev1) hipEventDestroy(tr.ev1);
+        if (tr.stream) hipStreamDestroy(tr.stream);
+    }
+    hipFree(c->bed); hipFree(c->group);
+    delete c;
+    return GMRM_OK;
+}
+
+int gmrm_ctx_sync(gmrm_ctx* c) {
+    if (!c) return fail(GMRM_EINVAL, "null context");
+    HIPCHK(hipSetDevice(c->device));
+    for (auto& tr : c->tr) HIPCHK(hipStreamSynchronize(tr.stream));
+    return GMRM_OK;
+}
+
+int gmrm_upload_bed(gmrm_ctx* c, const uint8_t* cols, size_t first, size_t n) {
+    if (!c || !cols) return fail(GMRM_EINVAL, "null argument");
+    if (first + n > (size_t)c->M) return fail(GMRM_EINVAL, "marker range outside this context's block");
+    if (n == 0) return GMRM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy2D(c->bed + first * c->stride, c->stride, cols, c->mbytes, c->mbytes, n, hipMemcpyHostToDevice));
+    c->have_bed = true;
+    for (auto& tr : c->tr) tr.have_stats = false;
+    return GMRM_OK;
+}
+
+int gmrm_download_bed(gmrm_ctx* c, uint8_t* cols, size_t first, size_t n) {
+    if (!c || !cols) return fail(GMRM_EINVAL, "null argument");
+    if (first + n > (size_t)c->M) return fail(GMRM_EINVAL, "marker range outside this context's block");
+    if (n == 0) return GMRM_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy2D(cols, c->mbytes, c->bed + first * c->stride, c->stride, c->mbytes, n, hipMemcpyDeviceToHost));
+    return GMRM_OK;
+}
+
+int gmrm_synth_bed(gmrm_ctx* c, uint64_t seed, double maf, double miss_rate) {
+    if (!c) return fail(GMRM_EINVAL, "null context");
+    if (!(maf > 0.0 && maf < 1.0) || !(miss_rate >= 0.0 && miss_rate < 1.0)) return fail(GMRM_EINVAL, "bad maf / miss_rate");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(launch_synth(c->bed, c->stride, c->N, c->M, c->S, seed, maf, miss_rate, c->tr[0].stream));
+    HIPCHK(hipStreamSynchronize(c->tr[0].stream));
+    c->have_bed = true;
+    for (auto& tr : c->tr) tr.have_stats = false;
+    return GMRM_OK;
+}
+
+int gmrm_upload_trait(gmrm_ctx* c, int t, const double* eps, const uint8_t* mask4, int nonas) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!eps || !mask4) return fail(GMRM_EINVAL, "null argument");
+    if (nonas < 2 || nonas > c->N) return fail(GMRM_EINVAL, "nonas out of range");
+    HIPCHK(hipSetDevice(c->device));
+    Trait& tr = c->tr[t];
+    // 2-bit NA mask in the genotype layout: field 11 = phenotype present (na_lut == 1.0,
+    // src/na_lut.hpp:3-68), 00 = NA or beyond N
+    std::vector<uint8_t> m2(c->stride, 0);
+    for (size_t b = 0; b < c->mbytes; b++) {
+        uint8_t v = 0;
+        for (int k = 0; k < 4; k++)
+            if ((mask4[b] >> k) & 1) v |= (uint8_t)(3u << (2 * k));
+        m2[b] = v;
+    }
+    HIPCHK(hipMemcpy(tr.namask2, m2.data(), c->stride, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(tr.eps, 0, 4 * c->stride * sizeof(double)));
+    HIPCHK(hipMemcpy(tr.eps, eps, 4 * c->mbytes * sizeof(double), hipMemcpyHostToDevice));
+    tr.nonas = nonas;
+    tr.have_trait = true;
+    tr.have_stats = false;
+    return GMRM_OK;
+}
+
+int gmrm_download_eps(gmrm_ctx* c, int t, double* eps) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!eps) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->tr[t].stream));
+    HIPCHK(hipMemcpy(eps, c->tr[t].eps, 4 * c->mbytes * sizeof(double), hipMemcpyDeviceToHost));
+    return GMRM_OK;
+}
+
+int gmrm_upload_eps(gmrm_ctx* c, int t, const double* eps) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!eps) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->tr[t].stream));
+    HIPCHK(hipMemcpy(c->tr[t].eps, eps, 4 * c->mbytes * sizeof(double), hipMemcpyHostToDevice));
+    return GMRM_OK;
+}
+
+static int need_trait(gmrm_ctx* c, int t, bool bed) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!c->tr[t].have_trait) return fail(GMRM_ESTATE, "phenotype not uploaded (gmrm_upload_trait)");
+    if (bed && !c->have_bed) return fail(GMRM_ESTATE, "genotypes not uploaded (gmrm_upload_bed / gmrm_synth_bed)");
+    return GMRM_OK;
+}
+
+int gmrm_marker_stats(gmrm_ctx* c, int t) {
+    if (int r = need_trait(c, t, true)) return r;
+    HIPCHK(hipSetDevice(c->device));
+    Trait& tr = c->tr[t];
+    HIPCHK(launch_marker_stats(c->bed, tr.namask2, c->stride, c->M, tr.nonas, tr.mave, tr.msig, tr.stream));
+    HIPCHK(hipStreamSynchronize(tr.stream));
+    tr.have_stats = true;
+    return GMRM_OK;
+}
+
+int gmrm_get_marker_stats(gmrm_ctx* c, int t, double* mave, double* msig) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!c->tr[t].have_stats) return fail(GMRM_ESTATE, "marker statistics not computed");
+    HIPCHK(hipSetDevice(c->device));
+    if (mave) HIPCHK(hipMemcpy(mave, c->tr[t].mave, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost));
+    if (msig) HIPCHK(hipMemcpy(msig, c->tr[t].msig, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost));
+    return GMRM_OK;
+}
+
+int gmrm_set_marker_stats(gmrm_ctx* c, int t, const double* mave, const double* msig) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!mave || !msig) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->tr[t].mave, mave, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->tr[t].msig, msig, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice));
+    c->tr[t].have_stats = true;
+    return GMRM_OK;
+}
+
+int gmrm_dot(gmrm_ctx* c, int t, int mloc, double mu, double sigma_inv, double* num) {
+    if (int r = need_trait(c, t, true)) return r;
+    if (mloc < 0 || mloc >= c->M || !num) return fail(GMRM_EINVAL, "marker index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    Trait& tr = c->tr[t];
+    HIPCHK(hipMemsetAsync(tr.scratch, 0, 4 * sizeof(double), tr.stream));
+    HIPCHK(launch_dot(c->bed + (size_t)mloc * c->stride, tr.namask2, tr.eps, c->stride, tr.scratch, tr.stream));
+    double h[4];
+    HIPCHK(hipMemcpyAsync(h, tr.scratch, sizeof(h), hipMemcpyDeviceToHost, tr.stream));
+    HIPCHK(hipStreamSynchronize(tr.stream));
+    const double dpa = h[0] + h[1];
+    const double dpb = h[2] + h[3];
+    *num = sigma_inv * (dpa - mu * dpb);                       // bayes.cpp:765
+    return GMRM_OK;
+}
+
+int gmrm_update_eps(gmrm_ctx* c, int t, int mloc, const double* dbeta) {
+    if (int r = need_trait(c, t, true)) return r;
+    if (mloc < 0 || mloc >= c->M || !dbeta) return fail(GMRM_EINVAL, "marker index out of range");
+    HIPCHK(hipSetDevice(c->device));
+    Trait& tr = c->tr[t];
+    const double bs_ = dbeta[0] * dbeta[2];                    // phenotype.cpp:328-329
+    const double mdb = -dbeta[1];
+    const double v0 = (mdb * 1.0 + 2.0) * bs_;                 // phenotype.cpp:385-388 per 2-bit code
+    const double v1 = (mdb * 0.0 + 0.0) * bs_;
+    const double v2 = (mdb * 1.0 + 1.0) * bs_;
+    const double v3 = (mdb * 1.0 + 0.0) * bs_;
+    HIPCHK(launch_update(tr.eps, c->bed + (size_t)mloc * c->stride, tr.namask2, c->stride, v0, v1, v2, v3, tr.stream));
+    HIPCHK(hipStreamSynchronize(tr.stream));
+    return GMRM_OK;
+}
+
+int gmrm_offset_eps(gmrm_ctx* c, int t, double offset) {
+    if (int r = need_trait(c, t, false)) return r;
+    HIPCHK(hipSetDevice(c->device));
+    Trait& tr = c->tr[t];
+    HIPCHK(launch_offset(tr.eps, tr.namask2, c->stride, offset, tr.stream));
+    HIPCHK(hipStreamSynchronize(tr.stream));
+    return GMRM_OK;
+}
+
+static int sumsq_common(gmrm_ctx* c, int t, bool masked, size_t n, double* out, double* maxabs) {
+    HIPCHK(hipSetDevice(c->device));
+    Trait& tr = c->tr[t];
+    HIPCHK(hipMemsetAsync(tr.scratch, 0, 4 * sizeof(double), tr.stream));
+    HIPCHK(launch_sumsq(tr.eps, masked ? tr.namask2 : nullptr, n, tr.scratch, tr.scratch + 2, tr.stream));
+    double h[3];
+    HIPCHK(hipMemcpyAsync(h, tr.scratch, sizeof(h), hipMemcpyDeviceToHost, tr.stream));
+    HIPCHK(hipStreamSynchronize(tr.stream));
+    *out = h[0] + h[1];
+    if (maxabs) *maxabs = h[2];
+    return GMRM_OK;
+}
+
+int gmrm_sumsqr(gmrm_ctx* c, int t, double* out) {
+    if (int r = need_trait(c, t, false)) return r;
+    if (!out) return fail(GMRM_EINVAL, "null argument");
+    double mx = 0.0;
+    if (int r = sumsq_common(c, t, false, (size_t)c->N, out, &mx)) return r;     // phenotype.cpp:257: i < N
+    if (!(mx < gm::EPS_ABS_LIMIT))
+        return fail(GMRM_EKERNEL, "|residual| reached 2^8: outside the range of the exact-summation bins");
+    return GMRM_OK;
+}
+
+int gmrm_eps_sigma(gmrm_ctx* c, int t, double* sigmae) {
+    if (int r = need_trait(c, t, false)) return r;
+    if (!sigmae) return fail(GMRM_EINVAL, "null argument");
+    double s = 0.0;
+    if (int r = sumsq_common(c, t, true, 4 * c->mbytes, &s, nullptr)) return r;  // phenotype.cpp:453-457
+    *sigmae = s / (double)c->tr[t].nonas * 0.5;
+    return GMRM_OK;
+}
+
+int gmrm_set_groups(gmrm_ctx* c, const int* group_local) {
+    if (!c || !group_local) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->group, group_local, (size_t)c->M * sizeof(int), hipMemcpyHostToDevice));
+    c->have_groups = true;
+    return GMRM_OK;
+}
+
+int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
+    if (int r = need_trait(c, t, true)) return r;
+    if (!in || !in->order || !in->sigmag || !in->pi_est || !in->cva) return fail(GMRM_EINVAL, "null argument");
+    Trait& tr = c->tr[t];
+    if (!tr.have_stats) return fail(GMRM_ESTATE, "marker statistics not computed (gmrm_marker_stats)");
+    if (!c->have_groups) return fail(GMRM_ESTATE, "marker groups not set (gmrm_set_groups)");
+    if (tr.in_flight) return fail(GMRM_ESTATE, "a sweep of this phenotype is already in flight");
+    const int G = in->G, K = in->K;
+    if (G < 1 || G > GMAX || K < 2 || K > KMAX) return fail(GMRM_EINVAL, "G or K outside the supported range (G<=64, 2<=K<=8)");
+    if (in->rng_index < 0 || in->rng_index > 624) return fail(GMRM_EINVAL, "rng_index out of range");
+    if (!(in->sigmae > 0.0)) return fail(GMRM_EINVAL, "sigmae must be positive");
+    HIPCHK(hipSetDevice(c->device));
+    tr.G = G; tr.K = K;
+    if (c->M == 0) { tr.in_flight = true; tr.empty = true; return GMRM_OK; }
+    tr.empty = false;
+
+    // per-group tables of the Gibbs step, evaluated exactly as bayes.cpp:403-432 writes them
+    std::vector<double> tab((size_t)G * (1 + 3 * K), 0.0);
+    double* sg = tab.data();
+    double* denom = sg + G;
+    double* logpi = denom + (size_t)G * K;
+    double* mhl = logpi + (size_t)G * K;
+    const double nm1 = (double)(tr.nonas - 1);
+    for (int g = 0; g < G; g++) {
+        sg[g] = in->sigmag[g];
+        if (sg[g] == 0.0) continue;                            // bayes.cpp:396: group is skipped
+        const double sige_g = in->sigmae / sg[g];
+        const double sigg_e = 1.0 / sige_g;
+        for (int k = 0; k < K; k++) {
+            logpi[g * K + k] = std::log(in->pi_est[g * K + k]);
+            if (k > 0) {
+                const double cvai = 1.0 / in->cva[g * K + k];  // options.cpp:282
+                denom[g * K + k] = (double)(c->N - 1) + sige_g * cvai;
+                mhl[g * K + k] = -0.5 * std::log(sigg_e * nm1 * in->cva[g * K + k] + 1.0);
+            }
+        }
+    }
+    HIPCHK(hipMemcpyAsync(tr.tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, tr.stream));
+    HIPCHK(hipMemcpyAsync(tr.order, in->order, (size_t)c->M * sizeof(int), hipMemcpyHostToDevice, tr.stream));
+    HIPCHK(hipMemcpyAsync(tr.rng_state, in->rng_state, 624 * sizeof(uint32_t), hipMemcpyHostToDevice, tr.stream));
+    HIPCHK(hipMemcpyAsync(tr.rng_index, &in->rng_index, sizeof(int), hipMemcpyHostToDevice, tr.stream));
+    HIPCHK(hipMemsetAsync(tr.cnt, 0, 96 * sizeof(unsigned), tr.stream));
+    HIPCHK(hipMemsetAsync(tr.err, 0, 4 * sizeof(int), tr.stream));
+    HIPCHK(hipMemsetAsync(tr.stats, 0, 4 * sizeof(long long), tr.stream));
+
+    SweepArgs a{};
+    a.N = c->N; a.M = c->M; a.W = c->W; a.Wpad = c->Wpad; a.G = G; a.K = K;
+    a.stride = c->stride;
+    a.bed = c->bed; a.namask2 = tr.namask2; a.order = tr.order; a.group = c->group;
+    a.mave = tr.mave; a.msig = tr.msig;
+    a.betas_in = tr.betas[tr.cur]; a.betas_out = tr.betas[tr.cur ^ 1];
+    a.comp = tr.comp; a.acum = tr.acum; a.eps = tr.eps;
+    a.sigmag = tr.tab; a.denom = tr.tab + G; a.logpi = tr.tab + G + (size_t)G * K; a.mhl = tr.tab + G + 2 * (size_t)G * K;
+    a.sigmae = in->sigmae;
+    a.inv2sige = 1.0 / (2.0 * in->sigmae);                     // bayes.cpp:406
+    a.nm1 = nm1;
+    a.rng_state = tr.rng_state; a.rng_index = tr.rng_index;
+    a.cass = tr.cass; a.stats = tr.stats; a.err = tr.err;
+    a.P = tr.P; a.Tt = tr.Tt; a.cnt = tr.cnt;
+    a.batch_init = c->batch_init;
+    // Phenotypes that do not fit side by side share stream 0 and run one after another.
+    hipStream_t st = c->concurrent ? tr.stream : c->tr[0].stream;
+    if (!c->concurrent && t != 0) HIPCHK(hipStreamSynchronize(tr.stream));   // uploads above done
+    HIPCHK(hipEventRecord(tr.ev0, st));
+    HIPCHK(launch_sweep(a, c->R, st));
+    HIPCHK(hipEventRecord(tr.ev1, st));
+    tr.launch_stream = st;
+    tr.in_flight = true;
+    return GMRM_OK;
+}
+
+int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
+    if (int r = ctx_check_t(c, t)) return r;
+    Trait& tr = c->tr[t];
+    if (!tr.in_flight) return fail(GMRM_ESTATE, "no sweep in flight for this phenotype");
+    tr.in_flight = false;
+    if (tr.empty) {
+        if (out) { out->n_updates = 0; out->n_batches = 0; out->device_ms = 0.0;
+                   if (out->cass) std::memset(out->cass, 0, sizeof(int) * (size_t)tr.G * tr.K); }
+        return GMRM_OK;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(tr.launch_stream));
+    int err[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(err, tr.err, sizeof(err), hipMemcpyDeviceToHost));
+    if (err[0] == 1) return fail(GMRM_EKERNEL, "sweep kernel: a grid-wide wait timed out (workgroups not co-resident?)");
+    if (err[0] == 2) return fail(GMRM_EKERNEL, "sweep kernel: RNG window exhausted inside one batch");
+    tr.cur ^= 1;
+    if (out) {
+        long long st[4];
+        HIPCHK(hipMemcpy(st, tr.stats, sizeof(st), hipMemcpyDeviceToHost));
+        out->n_updates = st[0]; out->n_batches = st[1];
+        if (out->cass) HIPCHK(hipMemcpy(out->cass, tr.cass, sizeof(int) * (size_t)tr.G * tr.K, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out->rng_state, tr.rng_state, 624 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&out->rng_index, tr.rng_index, sizeof(int), hipMemcpyDeviceToHost));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, tr.ev0, tr.ev1));
+        out->device_ms = ms;
+    }
+    return GMRM_OK;
+}
+
+int gmrm_get_betas(gmrm_ctx* c, int t, double* betas) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!betas) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(betas, c->tr[t].betas[c->tr[t].cur], (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost));
+    return GMRM_OK;
+}
+int gmrm_set_betas(gmrm_ctx* c, int t, const double* betas) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!betas) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->tr[t].betas[c->tr[t].cur], betas, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice));
+    return GMRM_OK;
+}
+int gmrm_get_comp(gmrm_ctx* c, int t, int* comp) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!comp) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(comp, c->tr[t].comp, (size_t)c->M * sizeof(int), hipMemcpyDeviceToHost));
+    return GMRM_OK;
+}
+int gmrm_get_acum(gmrm_ctx* c, int t, double* acum) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!acum) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(acum, c->tr[t].acum, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost));
+    return GMRM_OK;
+}
+
+int gmrm_eps_snapshot(gmrm_ctx* c, int t) {
+    if (int r = need_trait(c, t, false)) return r;
+    HIPCHK(hipSetDevice(c->device));
+    Trait& tr = c->tr[t];
+    HIPCHK(hipMemcpyAsync(tr.eps_start, tr.eps, 4 * c->stride * sizeof(double), hipMemcpyDeviceToDevice, tr.stream));
+    HIPCHK(hipStreamSynchronize(tr.stream));
+    return GMRM_OK;
+}
+int gmrm_eps_delta_export(gmrm_ctx* c, int t, double* dev_q) {
+    if (int r = need_trait(c, t, false)) return r;
+    if (!dev_q) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    Trait& tr = c->tr[t];
+    HIPCHK(launch_delta_export(tr.eps, tr.eps_start, dev_q, 4 * c->mbytes, tr.stream));
+    HIPCHK(hipStreamSynchronize(tr.stream));
+    return GMRM_OK;
+}
+int gmrm_eps_delta_import(gmrm_ctx* c, int t, const double* dev_q) {
+    if (int r = need_trait(c, t, false)) return r;
+    if (!dev_q) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    Trait& tr = c->tr[t];
+    HIPCHK(launch_delta_import(tr.eps, tr.eps_start, dev_q, 4 * c->mbytes, tr.stream));
+    HIPCHK(hipStreamSynchronize(tr.stream));
+    return GMRM_OK;
+}
+
+}  // extern "C"

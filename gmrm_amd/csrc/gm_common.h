@@ -1,0 +1,109 @@
+// gm_common.h -- arithmetic building blocks shared by the host C++ and the HIP device
+// code of libgmrm_hip: the 2-level pre-rounding that makes every reduction on the path
+// order-independent, the path's exp(), and the 2-bit genotype decode rule.
+//
+// Everything here is a fixed sequence of IEEE-754 binary64 operations (add, mul, fma,
+// div, sqrt) so that a CPU and a gfx950 evaluation give the same bits.  The library is
+// built with -ffp-contract=off: an a*b+c written as two operations stays two roundings.
+#pragma once
+#include <cstdint>
+#include <cmath>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GM_HD __host__ __device__ __forceinline__
+#else
+#define GM_HD inline
+#endif
+
+namespace gm {
+
+// ---- genotype decode: reference src/dotp_lut.hpp (generator src/lut/mk_lut.cpp:25-33,54-62)
+// 2-bit code c of individual k in a byte = (byte >> 2k) & 3:
+//   c = 0 -> (a,b) = (2,1);  c = 1 -> (0,0) missing;  c = 2 -> (1,1);  c = 3 -> (0,1)
+GM_HD double code_a(int c) { return c == 0 ? 2.0 : (c == 2 ? 1.0 : 0.0); }
+GM_HD double code_b(int c) { return c == 1 ? 0.0 : 1.0; }
+
+// ---- order-independent summation -------------------------------------------------
+// split2(x): q1 = x rounded to a multiple of 2^-22, q2 = (x - q1) rounded to a multiple
+// of 2^-53, remainder (< 2^-54) dropped.  For |x| < 2^8 and <= 2^22 terms scaled by
+// a in {0,1,2}, every partial sum of a*q1 (and of a*q2) is exactly representable, so the
+// totals do not depend on the order of accumulation (thread, wavefront, workgroup, GPU).
+constexpr double SPLIT_C1 = 0x1.8p+30;   // 1.5 * 2^(52-22)
+constexpr double SPLIT_C2 = 0x1.8p-1;    // 1.5 * 2^(52-53)
+constexpr double SPLIT_S1 = 0x1.8p+38;   // squares (< 2^16): grid 2^-14
+constexpr double SPLIT_S2 = 0x1.8p+7;    //                   grid 2^-45
+constexpr double EPS_ABS_LIMIT = 256.0;  // |residual| bound the exactness argument needs
+constexpr int    MAX_LOG2_N = 22;        // individuals <= 2^22
+
+GM_HD void split2(double x, double& q1, double& q2) {
+    const double t = x + SPLIT_C1;
+    q1 = t - SPLIT_C1;
+    const double r = x - q1;
+    const double u = r + SPLIT_C2;
+    q2 = u - SPLIT_C2;
+}
+GM_HD void split2sq(double x, double& q1, double& q2) {
+    const double t = x + SPLIT_S1;
+    q1 = t - SPLIT_S1;
+    const double r = x - q1;
+    const double u = r + SPLIT_S2;
+    q2 = u - SPLIT_S2;
+}
+
+GM_HD double fma_(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(a, b, c);
+#else
+    return std::fma(a, b, c);
+#endif
+}
+
+// ---- the path's exp() --------------------------------------------------------------
+// Used where the reference calls exp() in the Gibbs step (bayes.cpp:441,472) and in the
+// ziggurat wedge tests.  Argument reduction by ln2 (hi/lo), degree-13 Taylor/Horner in
+// fma, scaling by two exact powers of two.  ~1 ulp.
+GM_HD double exp_(double x) {
+    if (x != x) return x;
+    if (x > 0x1.62e42fefa39efp+9) return __builtin_huge_val();
+    if (x < -0x1.74910d52d3052p+9) return 0.0;
+    const double t = x * 0x1.71547652b82fep+0;
+    const double kd = (t + 0x1.8p52) - 0x1.8p52;
+    double r = fma_(-kd, 0x1.62e42fee00000p-1, x);
+    r = fma_(-kd, 0x1.a39ef35793c76p-33, r);
+    double p = 0x1.6124613a86d09p-33;
+    p = fma_(p, r, 0x1.1eed8eff8d898p-29);
+    p = fma_(p, r, 0x1.ae64567f544e4p-26);
+    p = fma_(p, r, 0x1.27e4fb7789f5cp-22);
+    p = fma_(p, r, 0x1.71de3a556c734p-19);
+    p = fma_(p, r, 0x1.a01a01a01a01ap-16);
+    p = fma_(p, r, 0x1.a01a01a01a01ap-13);
+    p = fma_(p, r, 0x1.6c16c16c16c17p-10);
+    p = fma_(p, r, 0x1.1111111111111p-7);
+    p = fma_(p, r, 0x1.5555555555555p-5);
+    p = fma_(p, r, 0x1.5555555555555p-3);
+    p = fma_(p, r, 0x1.0000000000000p-1);
+    p = fma_(p, r, 1.0);
+    p = fma_(p, r, 1.0);
+    const int k = (int)kd;
+    const int k1 = k / 2, k2 = k - k1;
+    const double s1 = __builtin_bit_cast(double, (uint64_t)(k1 + 1023) << 52);
+    const double s2 = __builtin_bit_cast(double, (uint64_t)(k2 + 1023) << 52);
+    return (p * s1) * s2;
+}
+
+GM_HD uint32_t mt_temper(uint32_t y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+GM_HD uint32_t mt_twist1(uint32_t cur, uint32_t nxt, uint32_t far) {
+    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+    uint32_t v = far ^ (y >> 1);
+    if (y & 1u) v ^= 0x9908b0dfu;
+    return v;
+}
+
+}  // namespace gm

@@ -1,0 +1,61 @@
+// gm_host.h -- host-side structures behind the opaque handles of include/gmrm_hip.h.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace gm {
+
+// One phenotype's device-resident chain state (reference: class Phenotype,
+// src/phenotype.hpp:12-55) plus the sweep kernel's workspace.
+struct Trait {
+    double* eps = nullptr;          // Phenotype::epsilon_   [4*stride]
+    double* eps_start = nullptr;    // residual at sweep start (multi-GPU exchange)
+    uint8_t* namask2 = nullptr;     // Phenotype::mask4 expanded to 2 bits per individual [stride]
+    double* mave = nullptr;         // Phenotype::mave [M]
+    double* msig = nullptr;         // Phenotype::msig [M]
+    double* betas[2] = {nullptr, nullptr};   // Phenotype::betas [M], double-buffered per sweep
+    int cur = 0;
+    int* comp = nullptr;            // Phenotype::comp [M]
+    double* acum = nullptr;         // Phenotype::acum [M]
+    int nonas = 0;
+    bool have_trait = false, have_stats = false, in_flight = false, empty = false;
+    int G = 0, K = 0;
+    // sweep workspace
+    int* order = nullptr;
+    double* tab = nullptr;
+    uint32_t* rng_state = nullptr;
+    int* rng_index = nullptr;
+    int* cass = nullptr;
+    long long* stats = nullptr;
+    int* err = nullptr;
+    double* P = nullptr;
+    double* Tt = nullptr;
+    unsigned* cnt = nullptr;
+    double* scratch = nullptr;
+    hipStream_t stream = nullptr, launch_stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+int fail(int code, const std::string& msg);
+
+}  // namespace gm
+
+// One GPU, one contiguous block of markers, T phenotypes (reference: class Bayes,
+// src/bayes.hpp:84-105).
+struct gmrm_ctx {
+    int device = 0, N = 0, M = 0, Mt = 0, S = 0, T = 0;
+    size_t mbytes = 0, stride = 0;
+    uint8_t* bed = nullptr;         // Bayes::bed_data, column stride padded to 16 bytes
+    int* group = nullptr;           // Bayes::group_index[S .. S+M)
+    std::vector<gm::Trait> tr;
+    int num_cu = 0, R = 0, W = 0, Wpad = 0;
+    bool concurrent = true, have_bed = false, have_groups = false;
+    int batch_init = 16;
+};
+
+namespace gm {
+int ctx_check_t(const gmrm_ctx* c, int t);
+}

@@ -1,0 +1,69 @@
+// gm_internal.h -- declarations shared by the translation units of libgmrm_hip
+// (ops.hip: per-call kernels, sweep.hip: the persistent marker-loop kernel,
+//  capi.cpp: context + C ABI, sampler.cpp: host-side Bayes::process mirror).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace gm {
+
+constexpr int SW_TPB  = 256;   // threads per workgroup of the sweep kernel (4 wavefronts)
+constexpr int SW_GB   = 8;     // markers accumulated per register group
+constexpr int SW_BMAX = 64;    // markers per batch <= lanes of the sampling wavefront
+constexpr int SW_VMAX = SW_BMAX * 4;   // exchanged values per batch (sa1,sa2,sb1,sb2 per marker)
+constexpr int KMAX = 8;
+constexpr int GMAX = 64;
+
+// Arguments of the persistent sweep kernel (one chain = one phenotype on one GPU).
+struct SweepArgs {
+    int N, M, W, Wpad, G, K;
+    size_t stride;                 // bytes per marker column in HBM (ceil(N/4) padded to 16)
+    const uint8_t* bed;            // [M][stride] 2-bit genotypes
+    const uint8_t* namask2;        // [stride] 2-bit NA mask (11 = phenotype present)
+    const int* order;              // [M] visit order (local marker ids)
+    const int* group;              // [M] group of each local marker
+    const double* mave;            // [M]
+    const double* msig;            // [M]
+    const double* betas_in;        // [M] effects before this sweep
+    double* betas_out;             // [M] effects after this sweep
+    int* comp;                     // [M]
+    double* acum;                  // [M]
+    double* eps;                   // [4*stride] residual, in/out
+    const double* sigmag;          // [G]
+    const double* denom;           // [G*K], entry k (k>=1) = (N-1) + sigmae/sigmag * cvai[k]
+    const double* logpi;           // [G*K] log(pi_est)
+    const double* mhl;             // [G*K] -0.5*log(sigmag/sigmae*(nonas-1)*cva + 1)
+    double sigmae, inv2sige, nm1;
+    uint32_t* rng_state;           // [624] in/out
+    int* rng_index;                // in/out
+    int* cass;                     // [G*K] out
+    long long* stats;              // [4] out: updates, batches, max batch, spare
+    int* err;                      // out: 0 ok
+    double* P;                     // [SW_VMAX][Wpad] per-workgroup partial sums
+    double* Tt;                    // [SW_VMAX] totals
+    unsigned* cnt;                 // [96] arrival counters / abort word, zeroed per launch
+    int batch_init;
+};
+
+// sweep.hip
+hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st);
+int  sweep_pick_R(size_t stride, int max_wg, int* W_out);   // bytes per thread, or -1
+size_t sweep_lds_bytes();
+
+// ops.hip
+hipError_t launch_dot(const uint8_t* col, const uint8_t* namask2, const double* eps, size_t stride,
+                      double* out4 /*zeroed*/, hipStream_t st);
+hipError_t launch_update(double* eps, const uint8_t* col, const uint8_t* namask2, size_t stride,
+                         double v0, double v1, double v2, double v3, hipStream_t st);
+hipError_t launch_offset(double* eps, const uint8_t* namask2, size_t stride, double off, hipStream_t st);
+hipError_t launch_sumsq(const double* eps, const uint8_t* namask2 /*or null*/, size_t n, double* out2 /*zeroed*/,
+                        double* outmax, hipStream_t st);
+hipError_t launch_marker_stats(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, int nonas,
+                               double* mave, double* msig, hipStream_t st);
+hipError_t launch_synth(uint8_t* bed, size_t stride, int N, int M, int S, uint64_t seed,
+                        double maf, double miss, hipStream_t st);
+hipError_t launch_delta_export(const double* eps, const double* start, double* q, size_t n4, hipStream_t st);
+hipError_t launch_delta_import(double* eps, const double* start, const double* q, size_t n4, hipStream_t st);
+
+}  // namespace gm

@@ -1,0 +1,285 @@
+// ops.hip -- the reference's per-call kernels as gfx950 HIP kernels, one per member
+// function on the hot path (file:line relative to /root/reference/):
+//   k_dot           Bayes::dot_product               src/bayes.cpp:709-770 (active 749-766)
+//   k_update        Phenotype::update_epsilon        src/phenotype.cpp:326-393 (active 375-390)
+//   k_offset        Phenotype::offset_epsilon        src/phenotype.cpp:395-411
+//   k_sumsq         Phenotype::epsilon_sumsqr        src/phenotype.cpp:251-261
+//                   Phenotype::update_epsilon_sigma  src/phenotype.cpp:432-459
+//   k_marker_stats  PhenMgr::compute_markers_statistics  src/phenotype.cpp:466-556
+// plus the synthetic-genotype generator and the residual-exchange helpers.
+//
+// All are HBM-streaming byte/word kernels: coalesced 4..16-byte loads of the 2-bit column,
+// the 4-entry (a,b) genotype table staged in LDS (the reference's 256x4 dotp_lut rows are
+// four copies of these 4 entries, one per 2-bit field), wavefront shuffle reductions.  The
+// sums are accumulated on pre-rounded bins (gm_common.h split2), hence exactly and in any
+// order, so the f64 atomics that combine workgroups do not make results run-dependent.
+#include "gm_common.h"
+#include "gm_internal.h"
+
+namespace gm {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- dot: out4 += {sum a*q1, sum a*q2, sum b*q1, sum b*q2} over the column ----------
+__global__ __launch_bounds__(256) void k_dot(const uint8_t* __restrict__ col, const double* __restrict__ eps,
+                                             size_t nwords, double* out4) {
+    __shared__ double2 lut[4];
+    __shared__ double red[4][4];
+    if (threadIdx.x < 4) lut[threadIdx.x] = make_double2(code_a(threadIdx.x), code_b(threadIdx.x));
+    __syncthreads();
+    double sa1 = 0.0, sa2 = 0.0, sb1 = 0.0, sb2 = 0.0;
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(col);
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t word = cw[w];
+        const double* e = eps + w * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            double q1, q2;
+            split2(e[k], q1, q2);
+            const double2 ab = lut[(word >> (2 * k)) & 3u];
+            sa1 = fma_(ab.x, q1, sa1); sa2 = fma_(ab.x, q2, sa2);
+            sb1 = fma_(ab.y, q1, sb1); sb2 = fma_(ab.y, q2, sb2);
+        }
+    }
+    sa1 = wave_sum(sa1); sa2 = wave_sum(sa2); sb1 = wave_sum(sb1); sb2 = wave_sum(sb2);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[wave][0] = sa1; red[wave][1] = sa2; red[wave][2] = sb1; red[wave][3] = sb2; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        unsafeAtomicAdd(&out4[threadIdx.x], v);
+    }
+}
+
+hipError_t launch_dot(const uint8_t* col, const uint8_t*, const double* eps, size_t stride, double* out4,
+                      hipStream_t st) {
+    const size_t nwords = stride / 4;
+    int blocks = (int)((nwords + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_dot, dim3(blocks), dim3(256), 0, st, col, eps, nwords, out4);
+    return hipGetLastError();
+}
+
+// ---- update: eps_i += val[code_i], code forced to 01 (-> val 0) where the phenotype is NA
+__global__ __launch_bounds__(256) void k_update(double* __restrict__ eps, const uint8_t* __restrict__ col,
+                                                const uint8_t* __restrict__ namask2, size_t nwords,
+                                                double v0, double v1, double v2, double v3) {
+    __shared__ double val[4];
+    if (threadIdx.x == 0) { val[0] = v0; val[1] = v1; val[2] = v2; val[3] = v3; }
+    __syncthreads();
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(col);
+    const uint32_t* mw = reinterpret_cast<const uint32_t*>(namask2);
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t m = mw[w];
+        const uint32_t word = (cw[w] & m) | (~m & 0x55555555u);
+        double* e = eps + w * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) e[k] += val[(word >> (2 * k)) & 3u];
+    }
+}
+
+hipError_t launch_update(double* eps, const uint8_t* col, const uint8_t* namask2, size_t stride,
+                         double v0, double v1, double v2, double v3, hipStream_t st) {
+    const size_t nwords = stride / 4;
+    int blocks = (int)((nwords + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_update, dim3(blocks), dim3(256), 0, st, eps, col, namask2, nwords, v0, v1, v2, v3);
+    return hipGetLastError();
+}
+
+// ---- offset: eps_i += off where the phenotype is present ------------------------------
+__global__ __launch_bounds__(256) void k_offset(double* __restrict__ eps, const uint8_t* __restrict__ namask2,
+                                                size_t nwords, double off) {
+    const uint32_t* mw = reinterpret_cast<const uint32_t*>(namask2);
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t m = mw[w];
+        double* e = eps + w * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if ((m >> (2 * k)) & 1u) e[k] += off;
+    }
+}
+
+hipError_t launch_offset(double* eps, const uint8_t* namask2, size_t stride, double off, hipStream_t st) {
+    const size_t nwords = stride / 4;
+    int blocks = (int)((nwords + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_offset, dim3(blocks), dim3(256), 0, st, eps, namask2, nwords, off);
+    return hipGetLastError();
+}
+
+// ---- sum of squares over eps[0..n): out2 += {sum q1, sum q2} of split2sq(eps_i^2);
+//      outmax = max |eps_i| (as ordered bits) for the range check of the exactness argument
+__global__ __launch_bounds__(256) void k_sumsq(const double* __restrict__ eps, const uint8_t* __restrict__ namask2,
+                                               size_t n, double* out2, unsigned long long* outmax) {
+    __shared__ double red[4][2];
+    __shared__ unsigned long long redm[4];
+    double s1 = 0.0, s2 = 0.0;
+    unsigned long long mx = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double x = eps[i];
+        if (namask2 && !((namask2[i >> 2] >> (2 * (i & 3))) & 1u)) x = 0.0;   // eps^2 * na_lut (phenotype.cpp:455)
+        double q1, q2;
+        split2sq(x * x, q1, q2);
+        s1 += q1; s2 += q2;
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(x));
+        mx = b > mx ? b : mx;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(mx, o, 64);
+        mx = other > mx ? other : mx;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[wave][0] = s1; red[wave][1] = s2; redm[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x < 2) unsafeAtomicAdd(&out2[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x]
+                                                              + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x == 2) {
+        unsigned long long m = redm[0];
+        for (int w = 1; w < 4; w++) m = redm[w] > m ? redm[w] : m;
+        atomicMax(outmax, m);
+    }
+}
+
+hipError_t launch_sumsq(const double* eps, const uint8_t* namask2, size_t n, double* out2, double* outmax,
+                        hipStream_t st) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_sumsq, dim3(blocks), dim3(256), 0, st, eps, namask2, n, out2,
+                       reinterpret_cast<unsigned long long*>(outmax));
+    return hipGetLastError();
+}
+
+// ---- marker statistics: one wavefront per marker, genotype counts by popcount ---------
+// mave = (2*n0 + n2) / (n0 + n2 + n3);  msig = 1/sqrt((n0*v0^2 + n2*v2^2 + n3*v3^2)/(nonas-1))
+// with n_c = #{present individuals with code c}, v0 = 2-mave, v2 = 1-mave, v3 = 0-mave.
+__global__ __launch_bounds__(256) void k_marker_stats(const uint8_t* __restrict__ bed,
+                                                      const uint8_t* __restrict__ namask2, size_t stride, int M,
+                                                      int nonas, double* __restrict__ mave, double* __restrict__ msig) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    const uint4* col = reinterpret_cast<const uint4*>(bed + (size_t)m * stride);
+    const uint4* msk = reinterpret_cast<const uint4*>(namask2);
+    const size_t nvec = stride / 16;
+    int n0 = 0, n2 = 0, n3 = 0;
+    for (size_t v = lane; v < nvec; v += 64) {
+        const uint4 w4 = col[v];
+        const uint4 m4 = msk[v];
+        const uint32_t ww[4] = {w4.x, w4.y, w4.z, w4.w};
+        const uint32_t mm[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t p = mm[i] & 0x55555555u;
+            const uint32_t lo = ww[i] & 0x55555555u;
+            const uint32_t hi = (ww[i] >> 1) & 0x55555555u;
+            n0 += __popc(p & ~lo & ~hi);
+            n2 += __popc(p & ~lo & hi);
+            n3 += __popc(p & lo & hi);
+        }
+    }
+    n0 = wave_sum_i(n0); n2 = wave_sum_i(n2); n3 = wave_sum_i(n3);
+    if (lane == 0) {
+        const double suma = (double)(2ll * n0 + n2);
+        const double sumb = (double)((long long)n0 + n2 + n3);
+        const double av = suma / sumb;
+        const double v0 = 2.0 - av, v2 = 1.0 - av, v3 = 0.0 - av;
+        double s = (double)n0 * (v0 * v0);
+        s += (double)n2 * (v2 * v2);
+        s += (double)n3 * (v3 * v3);
+        mave[m] = av;
+        msig[m] = 1.0 / __builtin_sqrt(s / ((double)nonas - 1.0));
+    }
+}
+
+hipError_t launch_marker_stats(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, int nonas,
+                               double* mave, double* msig, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_marker_stats, dim3((M + 3) / 4), dim3(256), 0, st, bed, namask2, stride, M, nonas, mave, msig);
+    return hipGetLastError();
+}
+
+// ---- synthetic genotypes, keyed by (seed, global marker, byte) ------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ bed, size_t stride, int N, int M, int S,
+                                               uint64_t seed, uint32_t maf16, uint32_t miss16) {
+    const size_t mbytes = ((size_t)N + 3) / 4;
+    const size_t total = (size_t)M * stride;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i / stride, b = i % stride;
+        uint8_t out = 0;
+        if (b < mbytes) {
+            const uint64_t key = ((uint64_t)(S + m) * (uint64_t)mbytes + b) * 3ull;
+            const uint64_t za = mix64(seed + (key + 0) * 0x9E3779B97F4A7C15ull);
+            const uint64_t zb = mix64(seed + (key + 1) * 0x9E3779B97F4A7C15ull);
+            const uint64_t zm = mix64(seed + (key + 2) * 0x9E3779B97F4A7C15ull);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (b * 4 + k >= (size_t)N) break;          // pad bits stay 00 as PLINK writes them
+                const uint32_t ua = (uint32_t)(za >> (16 * k)) & 0xFFFFu;
+                const uint32_t ub = (uint32_t)(zb >> (16 * k)) & 0xFFFFu;
+                const uint32_t um = (uint32_t)(zm >> (16 * k)) & 0xFFFFu;
+                const int copies = (ua < maf16) + (ub < maf16);
+                uint32_t code = copies == 2 ? 0u : (copies == 1 ? 2u : 3u);
+                if (um < miss16) code = 1u;
+                out |= (uint8_t)(code << (2 * k));
+            }
+        }
+        bed[i] = out;
+    }
+}
+
+hipError_t launch_synth(uint8_t* bed, size_t stride, int N, int M, int S, uint64_t seed, double maf, double miss,
+                        hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    const uint32_t maf16 = (uint32_t)(maf * 65536.0);
+    const uint32_t miss16 = (uint32_t)(miss * 65536.0);
+    hipLaunchKernelGGL(k_synth, dim3(256 * 32), dim3(256), 0, st, bed, stride, N, M, S, seed, maf16, miss16);
+    return hipGetLastError();
+}
+
+// ---- residual exchange helpers -----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_delta_export(const double* __restrict__ eps, const double* __restrict__ start,
+                                                      double* __restrict__ q, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        double q1, q2;
+        split2(eps[i] - start[i], q1, q2);
+        q[i] = q1;
+        q[n4 + i] = q2;
+    }
+}
+__global__ __launch_bounds__(256) void k_delta_import(double* __restrict__ eps, const double* __restrict__ start,
+                                                      const double* __restrict__ q, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        eps[i] = start[i] + (q[i] + q[n4 + i]);
+}
+hipError_t launch_delta_export(const double* eps, const double* start, double* q, size_t n4, hipStream_t st) {
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_delta_export, dim3(blocks), dim3(256), 0, st, eps, start, q, n4);
+    return hipGetLastError();
+}
+hipError_t launch_delta_import(double* eps, const double* start, const double* q, size_t n4, hipStream_t st) {
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_delta_import, dim3(blocks), dim3(256), 0, st, eps, start, q, n4);
+    return hipGetLastError();
+}
+
+}  // namespace gm

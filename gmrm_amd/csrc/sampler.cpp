@@ -1,0 +1,278 @@
+// sampler.cpp -- host-side mirror of Bayes::process() (reference src/bayes.cpp:318-677)
+// around the marker loop: initial draws (322-335), per-iteration prologue (348-368), the
+// hyper-parameter updates (562-651) and the .csv record (src/xfiles.cpp:6-47).  The marker
+// loop itself (375-553) is the persistent HIP kernel behind gmrm_sweep_launch/finish.
+// All draws follow the RNG spec of gm_rng.h on the reference's two streams per phenotype
+// (dist_m: shuffling, dist_d: everything else; seeds src/bayes.cpp:796-803).
+#include "../../include/gmrm_hip.h"
+#include "gm_common.h"
+#include "gm_rng.h"
+#include "gm_internal.h"
+#include "gm_host.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+const double V0E = 0.0001, S02E = 0.0001, V0G = 0.0001, S02G = 0.0001;   // bayes.hpp:14-17
+
+struct Chain {                       // class Phenotype, the host-resident part
+    gm::Mt19937 dist_m, dist_d;
+    std::vector<int> midx, cass, m0;
+    std::vector<double> sigmag, pi_est, beta_sqn, betas;
+    double sigmae = 0.0, mu = 0.0, epssum = 0.0;
+    long long n_updates = 0, n_batches = 0;
+    double sweep_ms = 0.0;
+};
+
+}  // namespace
+
+struct gmrm_sampler {
+    gmrm_ctx* ctx = nullptr;
+    uint32_t seed = 0;
+    int rank = 0, nranks = 1, shuffle = 1, mimic_hydra = 0, G = 0, K = 0;
+    std::vector<double> cva, pi_prior;
+    std::vector<int> group_index, mtotgrp;
+    std::vector<Chain> ch;
+};
+
+using gm::fail;
+
+extern "C" {
+
+int gmrm_sampler_create(gmrm_sampler** out, gmrm_ctx* ctx, const gmrm_sampler_opts* o) {
+    if (!out || !ctx || !o || !o->cva || !o->group_index) return fail(GMRM_EINVAL, "null argument");
+    *out = nullptr;
+    const int G = o->G, K = o->K;
+    if (G < 1 || G > gm::GMAX || K < 2 || K > gm::KMAX) return fail(GMRM_EINVAL, "G or K outside the supported range (G<=64, 2<=K<=8)");
+    if (o->rank < 0 || o->nranks < 1 || o->rank >= o->nranks) return fail(GMRM_EINVAL, "bad rank / nranks");
+    if (o->mimic_hydra && ctx->T > 1) return fail(GMRM_EINVAL, "with mimic_hydra only a single phenotype can be processed"); // options.cpp:216-219
+    for (int i = 0; i < ctx->Mt; i++)
+        if (o->group_index[i] < 0 || o->group_index[i] >= G) return fail(GMRM_EINVAL, "group index outside [0, G)");
+    for (int g = 0; g < G; g++) {                                  // options.cpp:266-284
+        if (o->cva[g * K] != 0.0) return fail(GMRM_EINVAL, "first element of a group mixture must be 0.0");
+        for (int j = 1; j < K; j++)
+            if (!(o->cva[g * K + j] > o->cva[g * K + j - 1])) return fail(GMRM_EINVAL, "mixtures must be given in ascending order");
+    }
+    gmrm_sampler* s = new gmrm_sampler();
+    s->ctx = ctx; s->seed = o->seed; s->rank = o->rank; s->nranks = o->nranks;
+    s->shuffle = o->shuffle; s->mimic_hydra = o->mimic_hydra; s->G = G; s->K = K;
+    s->cva.assign(o->cva, o->cva + (size_t)G * K);
+    s->group_index.assign(o->group_index, o->group_index + ctx->Mt);
+    s->mtotgrp.assign(G, 0);
+    for (int i = 0; i < ctx->Mt; i++) s->mtotgrp[s->group_index[i]] += 1;         // bayes.cpp:807-809
+    s->pi_prior.assign((size_t)G * K, 0.0);
+    for (int g = 0; g < G; g++) {                                                  // bayes.hpp:37-47
+        double sum_cva = 0.0;
+        for (int j = 0; j < K - 1; j++) sum_cva += s->cva[g * K + j + 1];
+        s->pi_prior[g * K] = 0.5;
+        for (int j = 1; j < K; j++) s->pi_prior[g * K + j] = s->pi_prior[g * K] * s->cva[g * K + j] / sum_cva;
+    }
+    if (int r = gmrm_set_groups(ctx, s->group_index.data() + ctx->S)) { delete s; return r; }
+    s->ch.resize(ctx->T);
+    for (int t = 0; t < ctx->T; t++) {
+        Chain& c = s->ch[t];
+        if (!ctx->tr[t].have_stats)
+            if (int r = gmrm_marker_stats(ctx, t)) { delete s; return r; }        // bayes.cpp:788
+        c.dist_m.seed((uint32_t)(s->seed + (uint32_t)s->rank));                    // bayes.cpp:796-803
+        if (s->mimic_hydra) c.dist_d.seed((uint32_t)(s->seed + (uint32_t)s->rank * 1000u));
+        else                c.dist_d.seed((uint32_t)(s->seed + (uint32_t)(s->rank + 1) * 1000u));
+        c.midx.resize(ctx->M);
+        c.cass.assign((size_t)G * K, 0);
+        c.m0.assign(G, 0);
+        c.sigmag.assign(G, 0.0);
+        c.pi_est.assign((size_t)G * K, 0.0);
+        c.beta_sqn.assign(G, 0.0);
+        c.betas.assign(ctx->M, 0.0);
+    }
+    *out = s;
+    return GMRM_OK;
+}
+
+int gmrm_sampler_destroy(gmrm_sampler* s) { delete s; return GMRM_OK; }
+
+// bayes.cpp:322-335
+int gmrm_sampler_init(gmrm_sampler* s) {
+    if (!s) return fail(GMRM_EINVAL, "null sampler");
+    for (auto& c : s->ch) {
+        for (int i = 0; i < s->ctx->M; i++) c.midx[i] = i;                         // phenotype.cpp:308-312
+        for (int g = 0; g < s->G; g++) {
+            c.sigmag[g] = gm::rbeta(c.dist_d, 1.0, 1.0);
+            if (s->mtotgrp[g] == 0) c.sigmag[g] = 0.0;
+        }
+        c.pi_est = s->pi_prior;
+    }
+    return GMRM_OK;
+}
+
+// bayes.cpp:348-358: add the previous mu back, (it == 1) initial sigmae, draw the new mu
+int gmrm_sampler_draw_mu(gmrm_sampler* s, int it, double* mu_drawn) {
+    if (!s || !mu_drawn) return fail(GMRM_EINVAL, "null argument");
+    gmrm_ctx* ctx = s->ctx;
+    for (int t = 0; t < ctx->T; t++) {
+        Chain& c = s->ch[t];
+        if (int r = gmrm_offset_eps(ctx, t, c.mu)) return r;
+        if (it == 1)
+            if (int r = gmrm_eps_sigma(ctx, t, &c.sigmae)) return r;
+        const double nonas = (double)ctx->tr[t].nonas;
+        mu_drawn[t] = gm::norm(c.dist_d, c.epssum / nonas, c.sigmae / nonas);      // phenotype.cpp:279-282
+    }
+    return GMRM_OK;
+}
+
+// bayes.cpp:358-367 with the adopted mu, then the marker loop is launched (asynchronous)
+int gmrm_sampler_begin_sweep(gmrm_sampler* s, const double* mu_use) {
+    if (!s || !mu_use) return fail(GMRM_EINVAL, "null argument");
+    gmrm_ctx* ctx = s->ctx;
+    for (int t = 0; t < ctx->T; t++) {
+        Chain& c = s->ch[t];
+        c.mu = mu_use[t];
+        if (int r = gmrm_offset_eps(ctx, t, -c.mu)) return r;
+        if (s->shuffle) gm::shuffle(s->mimic_hydra ? c.dist_d : c.dist_m, c.midx.data(), ctx->M);   // phenotype.cpp:314-323
+        std::fill(c.m0.begin(), c.m0.end(), 0);
+        std::fill(c.cass.begin(), c.cass.end(), 0);
+        if (s->nranks > 1)
+            if (int r = gmrm_eps_snapshot(ctx, t)) return r;
+    }
+    for (int t = 0; t < ctx->T; t++) {
+        Chain& c = s->ch[t];
+        gmrm_sweep_in in{};
+        in.G = s->G; in.K = s->K;
+        in.order = c.midx.data();
+        in.sigmag = c.sigmag.data();
+        in.pi_est = c.pi_est.data();
+        in.cva = s->cva.data();
+        in.sigmae = c.sigmae;
+        std::memcpy(in.rng_state, c.dist_d.mt, sizeof(in.rng_state));
+        in.rng_index = c.dist_d.idx;
+        if (int r = gmrm_sweep_launch(ctx, t, &in)) return r;
+    }
+    return GMRM_OK;
+}
+
+// waits for the marker loops; local cass and beta_sqn (bayes.cpp:565-568)
+int gmrm_sampler_end_sweep(gmrm_sampler* s, int* cass, double* beta_sqn) {
+    if (!s) return fail(GMRM_EINVAL, "null sampler");
+    gmrm_ctx* ctx = s->ctx;
+    const int G = s->G, K = s->K;
+    int rc = GMRM_OK;
+    for (int t = 0; t < ctx->T; t++) {
+        Chain& c = s->ch[t];
+        gmrm_sweep_out out{};
+        out.cass = c.cass.data();
+        std::memcpy(out.rng_state, c.dist_d.mt, sizeof(out.rng_state));   // kept if M == 0
+        out.rng_index = c.dist_d.idx;
+        const bool empty = ctx->M == 0;
+        if (int r = gmrm_sweep_finish(ctx, t, &out)) { rc = r; continue; }
+        if (!empty) {
+            std::memcpy(c.dist_d.mt, out.rng_state, sizeof(out.rng_state));
+            c.dist_d.idx = out.rng_index;
+        }
+        c.n_updates = out.n_updates; c.n_batches = out.n_batches; c.sweep_ms = out.device_ms;
+        if (ctx->M > 0)
+            if (int r = gmrm_get_betas(ctx, t, c.betas.data())) { rc = r; continue; }
+        std::fill(c.beta_sqn.begin(), c.beta_sqn.end(), 0.0);
+        for (int i = 0; i < ctx->M; i++)
+            c.beta_sqn[s->group_index[ctx->S + i]] += c.betas[i] * c.betas[i];
+        if (cass) std::memcpy(cass + (size_t)t * G * K, c.cass.data(), sizeof(int) * (size_t)G * K);
+        if (beta_sqn) std::memcpy(beta_sqn + (size_t)t * G, c.beta_sqn.data(), sizeof(double) * (size_t)G);
+    }
+    return rc;
+}
+
+// bayes.cpp:590-651 with the (all-reduced) cass and beta_sqn
+int gmrm_sampler_epilogue(gmrm_sampler* s, const int* cass, const double* beta_sqn) {
+    if (!s || !cass || !beta_sqn) return fail(GMRM_EINVAL, "null argument");
+    gmrm_ctx* ctx = s->ctx;
+    const int G = s->G, K = s->K;
+    for (int t = 0; t < ctx->T; t++) {
+        Chain& c = s->ch[t];
+        std::memcpy(c.cass.data(), cass + (size_t)t * G * K, sizeof(int) * (size_t)G * K);
+        std::memcpy(c.beta_sqn.data(), beta_sqn + (size_t)t * G, sizeof(double) * (size_t)G);
+        for (int g = 0; g < G; g++) {
+            if (s->mtotgrp[g] == 0) continue;
+            c.m0[g] = s->mtotgrp[g] - c.cass[g * K + 0];
+            int cass_sum = 0;
+            for (int k = 0; k < K; k++) cass_sum += c.cass[g * K + k];
+            if (c.m0[g] == 0 || cass_sum == 0) { c.sigmag[g] = 0.0; continue; }
+            const double m0 = (double)c.m0[g];
+            c.sigmag[g] = gm::inv_scaled_chisq(c.dist_d, V0G + m0, (c.beta_sqn[g] * m0 + V0G * S02G) / (V0G + m0));
+            double sum = 0.0;                                                      // phenotype.cpp:227-237
+            for (int i = 0; i < K; i++) {
+                const double val = gm::rgamma(c.dist_d, (double)c.cass[g * K + i] + 1.0, 1.0);
+                c.pi_est[g * K + i] = val;
+                sum += val;
+            }
+            for (int i = 0; i < K; i++) c.pi_est[g * K + i] = c.pi_est[g * K + i] / sum;
+        }
+        double e_sqn = 0.0;
+        if (int r = gmrm_sumsqr(ctx, t, &e_sqn)) return r;                          // bayes.cpp:631
+        c.sigmae = gm::inv_scaled_chisq(c.dist_d, V0E + (double)ctx->N, (e_sqn + V0E * S02E) / (V0E + (double)ctx->N));
+    }
+    return GMRM_OK;
+}
+
+int gmrm_sampler_adopt(gmrm_sampler* s, int t, const double* sigmag, const double* pi_est, double sigmae) {
+    if (!s || !sigmag || !pi_est) return fail(GMRM_EINVAL, "null argument");
+    if (t < 0 || t >= s->ctx->T) return fail(GMRM_EINVAL, "phenotype index out of range");
+    Chain& c = s->ch[t];
+    c.sigmag.assign(sigmag, sigmag + s->G);
+    c.pi_est.assign(pi_est, pi_est + (size_t)s->G * s->K);
+    c.sigmae = sigmae;
+    return GMRM_OK;
+}
+
+int gmrm_sampler_iterate(gmrm_sampler* s, int it) {
+    if (!s) return fail(GMRM_EINVAL, "null sampler");
+    if (s->nranks != 1) return fail(GMRM_ESTATE, "gmrm_sampler_iterate is the single-shard form; use the split calls");
+    const int T = s->ctx->T;
+    std::vector<double> mu(T);
+    if (int r = gmrm_sampler_draw_mu(s, it, mu.data())) return r;
+    if (int r = gmrm_sampler_begin_sweep(s, mu.data())) return r;
+    std::vector<int> cass((size_t)T * s->G * s->K);
+    std::vector<double> bsq((size_t)T * s->G);
+    if (int r = gmrm_sampler_end_sweep(s, cass.data(), bsq.data())) return r;
+    return gmrm_sampler_epilogue(s, cass.data(), bsq.data());
+}
+
+int gmrm_sampler_get(gmrm_sampler* s, int t, gmrm_hyper* out) {
+    if (!s || !out) return fail(GMRM_EINVAL, "null argument");
+    if (t < 0 || t >= s->ctx->T) return fail(GMRM_EINVAL, "phenotype index out of range");
+    const Chain& c = s->ch[t];
+    std::memset(out, 0, sizeof(*out));
+    out->sigmae = c.sigmae; out->mu = c.mu;
+    int m0s = 0;
+    for (int g = 0; g < s->G; g++) m0s += c.m0[g];                                  // phenotype.cpp:98-103
+    out->m0_sum = m0s;
+    for (int g = 0; g < s->G; g++) out->sigmag[g] = c.sigmag[g];
+    for (int i = 0; i < s->G * s->K; i++) out->pi_est[i] = c.pi_est[i];
+    out->n_updates = c.n_updates; out->n_batches = c.n_batches; out->sweep_device_ms = c.sweep_ms;
+    return GMRM_OK;
+}
+
+// xfiles.cpp:17-42
+int gmrm_sampler_csv_line(gmrm_sampler* s, int t, int it, char* buf, size_t len) {
+    if (!s || !buf) return fail(GMRM_EINVAL, "null argument");
+    if (t < 0 || t >= s->ctx->T) return fail(GMRM_EINVAL, "phenotype index out of range");
+    const Chain& c = s->ch[t];
+    const int G = s->G, K = s->K;
+    size_t n = 0;
+    auto put = [&](int w) { if (w > 0) n += (size_t)w; };
+    put(std::snprintf(buf + n, n < len ? len - n : 0, "%5d, %4d", it, G));
+    double sigmag_sum = 0.0;
+    for (int i = 0; i < G; i++) put(std::snprintf(buf + n, n < len ? len - n : 0, ", %20.15f", c.sigmag[i]));
+    for (int i = 0; i < G; i++) sigmag_sum += c.sigmag[i];
+    int m0s = 0;
+    for (int g = 0; g < G; g++) m0s += c.m0[g];
+    put(std::snprintf(buf + n, n < len ? len - n : 0, ", %20.15f, %20.15f, %7d, %4d, %2d", c.sigmae,
+                      sigmag_sum / (c.sigmae + sigmag_sum), m0s, G, K));
+    for (int i = 0; i < G * K; i++) put(std::snprintf(buf + n, n < len ? len - n : 0, ", %20.15f", c.pi_est[i]));
+    put(std::snprintf(buf + n, n < len ? len - n : 0, "\n"));
+    if (n >= len) return fail(GMRM_EINVAL, "csv buffer too small");
+    return (int)n;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+"""Marker-sharded sampling over several GPUs of one node: one process per GPU,
+torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in CPU tests).
+
+The reference partitions markers over MPI ranks and exchanges every updated column at
+every marker step (src/bayes.cpp:495-553: Barrier, Allgather, 2x Allgatherv per step).
+Here each rank sweeps its own block against its own residual replica and the replicas are
+reconciled ONCE per sweep (DESIGN.md "Multi-GPU"):
+
+  1. every rank draws mu on its own stream; rank 0's draw is adopted          (broadcast, T doubles)
+  2. every rank launches its marker loop (persistent HIP kernel)               (no communication)
+  3. delta = eps - eps_start is pre-rounded into two exact bins and summed     (ONE all-reduce of
+     over ranks; exact, so the result does not depend on the reduction order    2*4*ceil(N/4) f64 per
+     RCCL picks                                                                 phenotype)
+  4. cass (int) is all-reduced; beta_sqn is all-gathered and summed in rank    (src/bayes.cpp:575-588)
+     order
+  5. every rank runs the hyper-parameter draws on its own stream, then adopts  (src/bayes.cpp:626,638,649)
+     rank 0's sigmag / pi_est / sigmae
+
+`engine` is anything with the Sampler/Context split-call surface (gmrm_amd.api); the CPU
+tests drive this same code with a stand-in engine to check the exchange logic under gloo.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class HipEngine:
+    """The product engine: gmrm_amd.Sampler + Context on this rank's GPU."""
+
+    def __init__(self, sampler, device):
+        self.s = sampler
+        self.ctx = sampler.ctx
+        self.T, self.G, self.K = self.ctx.T, sampler.G, sampler.K
+        self.n4 = 4 * self.ctx.mbytes
+        self.device = device
+        self._q = torch.empty(2 * self.n4, dtype=torch.float64, device=device)
+
+    def draw_mu(self, it):
+        return self.s.draw_mu(it)
+
+    def begin_sweep(self, mu):
+        self.s.begin_sweep(mu)
+
+    def end_sweep(self):
+        return self.s.end_sweep()
+
+    def delta_export(self, t):
+        torch.cuda.current_stream(self.device).synchronize()
+        self.ctx.eps_delta_export(t, self._q.data_ptr())
+        return self._q
+
+    def delta_import(self, t, q):
+        torch.cuda.current_stream(self.device).synchronize()
+        self.ctx.eps_delta_import(t, q.data_ptr())
+
+    def epilogue(self, cass, bsq):
+        self.s.epilogue(cass, bsq)
+
+    def get_hyper(self, t):
+        h = self.s.hyper(t)
+        return h.sigmag, h.pi_est, h.sigmae
+
+    def adopt(self, t, sigmag, pi, sigmae):
+        self.s.adopt(t, sigmag, pi, sigmae)
+
+    def small(self, arr):
+        return torch.as_tensor(arr, device=self.device)
+
+
+class ShardedDriver:
+    def __init__(self, engine, group=None):
+        self.e = engine
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def iterate(self, it):
+        e = self.e
+        T, G, K = e.T, e.G, e.K
+        mu = e.small(np.asarray(e.draw_mu(it), dtype=np.float64))
+        dist.broadcast(mu, src=0, group=self.group)
+        e.begin_sweep(mu.cpu().numpy())
+        cass, bsq = e.end_sweep()
+        for t in range(T):
+            q = e.delta_export(t)
+            dist.all_reduce(q, op=dist.ReduceOp.SUM, group=self.group)
+            e.delta_import(t, q)
+        cass_t = e.small(np.ascontiguousarray(cass, dtype=np.int32))
+        dist.all_reduce(cass_t, op=dist.ReduceOp.SUM, group=self.group)
+        bsq_t = e.small(np.ascontiguousarray(bsq, dtype=np.float64))
+        parts = [torch.empty_like(bsq_t) for _ in range(self.world)]
+        dist.all_gather(parts, bsq_t, group=self.group)
+        total = parts[0].clone()
+        for p in parts[1:]:
+            total += p                                  # rank order, as a sequential MPI_SUM would
+        e.epilogue(cass_t.cpu().numpy(), total.cpu().numpy())
+        for t in range(T):
+            sg, pi, se = e.get_hyper(t)
+            pack = e.small(np.concatenate([np.asarray(sg, dtype=np.float64), np.asarray(pi, dtype=np.float64).ravel(),
+                                           [float(se)]]))
+            dist.broadcast(pack, src=0, group=self.group)
+            p = pack.cpu().numpy()
+            e.adopt(t, p[:G], p[G:G + G * K], float(p[-1]))

@@ -1,0 +1,182 @@
+/*
+ * gmrm_hip.h -- C ABI of libgmrm_hip.so: the MI355X (gfx950) implementation of gmrm's
+ * per-marker Gibbs update hot path.
+ *
+ * The reference has no plugin / FFI boundary: the path sits behind ordinary C++ member
+ * calls made from Bayes::process() (reference src/bayes.cpp:318-677).  Each entry point
+ * below names the member it replaces (file:line relative to /root/reference/).  Plain
+ * pointers and sizes only; no torch / HIP types.  INTEGRATION.md shows the call-site
+ * patch a gmrm maintainer would apply.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative GMRM_E* code on failure;
+ *     gmrm_last_error() returns a message for the calling thread's last failure.
+ *   - the reference aborts (MPI_Abort / exit(1), src/utilities.cpp:15-30) on failure and
+ *     has no return codes; callers that want that behaviour abort on a non-zero return.
+ *   - the caller owns every host buffer; the context owns every device buffer, except
+ *     where a function takes a `dev_*` pointer (caller-owned device memory, e.g. a
+ *     torch tensor's data_ptr() used for the RCCL exchange).
+ *   - one context = one GPU = one contiguous block of markers (src/bayes.cpp:903-925)
+ *     x T phenotypes.  Not thread-safe per context (as the reference's objects).
+ *   - there is NO CPU fallback: without a HIP device every compute entry fails with
+ *     GMRM_ENODEV.
+ */
+#ifndef GMRM_HIP_H
+#define GMRM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMRM_OK        0
+#define GMRM_EINVAL   -1   /* bad argument / shape */
+#define GMRM_ENODEV   -2   /* no usable HIP device */
+#define GMRM_EHIP     -3   /* HIP runtime error (message in gmrm_last_error) */
+#define GMRM_ENOMEM   -4
+#define GMRM_ESTATE   -5   /* call order violated (e.g. sweep before marker_stats) */
+#define GMRM_EKERNEL  -6   /* a device-side check failed (timeout word, RNG window, range) */
+#define GMRM_EIO      -7
+
+#define GMRM_KMAX      8   /* mixture components per group supported on device */
+
+typedef struct gmrm_ctx gmrm_ctx;
+typedef struct gmrm_sampler gmrm_sampler;
+
+const char* gmrm_last_error(void);
+int  gmrm_abi_version(void);
+int  gmrm_device_count(void);            /* 0 when no HIP device is visible */
+
+/* ------------------------------------------------------------------------------------
+ * Context: Bayes ctor + setup_processing() (src/bayes.hpp:20-56, src/bayes.cpp:774-812).
+ *   N        individuals (invariant over ranks)        Bayes::N
+ *   M        markers held by this context              Bayes::M
+ *   Mt, S    total markers / first global marker       Bayes::Mt, Bayes::S
+ *   T        phenotypes                                PhenMgr::phens.size()
+ * ---------------------------------------------------------------------------------- */
+int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int T);
+int gmrm_ctx_destroy(gmrm_ctx* ctx);
+int gmrm_ctx_sync(gmrm_ctx* ctx);                      /* wait for every stream of ctx */
+
+/* Genotypes: Bayes::load_genotype (src/bayes.cpp:867-900).  `cols` is marker-major,
+ * ceil(N/4) bytes per marker, PLINK 2-bit codes LSB first (no 3-byte magic). */
+int gmrm_upload_bed(gmrm_ctx* ctx, const uint8_t* cols, size_t first_marker, size_t n_markers);
+int gmrm_download_bed(gmrm_ctx* ctx, uint8_t* cols, size_t first_marker, size_t n_markers);
+/* Synthetic genotypes generated on the device, keyed by (seed, global marker, individual):
+ * copies of A1 ~ Binomial(2, maf) (example/data_sim.R:15), code 01 with prob. miss_rate. */
+int gmrm_synth_bed(gmrm_ctx* ctx, uint64_t seed, double maf, double miss_rate);
+
+/* Phenotype t: Phenotype ctor + read_file (src/phenotype.cpp:18-55,587-673): the centred,
+ * scaled residual eps[4*ceil(N/4)] (0 at NA and in the tail), mask4[ceil(N/4)], nonas. */
+int gmrm_upload_trait(gmrm_ctx* ctx, int t, const double* eps, const uint8_t* mask4, int nonas);
+int gmrm_download_eps(gmrm_ctx* ctx, int t, double* eps);
+int gmrm_upload_eps(gmrm_ctx* ctx, int t, const double* eps);
+
+/* ------------------------------------------------------------------------------------
+ * The reference's per-call kernels, one entry each.
+ * ---------------------------------------------------------------------------------- */
+/* PhenMgr::compute_markers_statistics (src/phenotype.cpp:466-556), phenotype t. */
+int gmrm_marker_stats(gmrm_ctx* ctx, int t);
+int gmrm_get_marker_stats(gmrm_ctx* ctx, int t, double* mave, double* msig);
+int gmrm_set_marker_stats(gmrm_ctx* ctx, int t, const double* mave, const double* msig);
+/* double Bayes::dot_product(mloc, phen, mu, sigma_inv) (src/bayes.hpp:66, src/bayes.cpp:709-770) */
+int gmrm_dot(gmrm_ctx* ctx, int t, int mloc, double mu, double sigma_inv, double* num);
+/* void Phenotype::update_epsilon(const double* dbeta[3], bed) (src/phenotype.hpp:153,
+ * src/phenotype.cpp:326-393); dbeta3 = {dbeta, mave, msig}; the column is marker mloc. */
+int gmrm_update_eps(gmrm_ctx* ctx, int t, int mloc, const double* dbeta3);
+/* void Phenotype::offset_epsilon(double) (src/phenotype.hpp:108, src/phenotype.cpp:395-411) */
+int gmrm_offset_eps(gmrm_ctx* ctx, int t, double offset);
+/* double Phenotype::epsilon_sumsqr() (src/phenotype.hpp:154, src/phenotype.cpp:251-261) */
+int gmrm_sumsqr(gmrm_ctx* ctx, int t, double* out);
+/* void Phenotype::update_epsilon_sigma() (src/phenotype.hpp:110, src/phenotype.cpp:432-459);
+ * *sigmae receives the value set_sigmae() would. */
+int gmrm_eps_sigma(gmrm_ctx* ctx, int t, double* sigmae);
+
+/* ------------------------------------------------------------------------------------
+ * Fused marker loop: the body of `for (mrki...)` in Bayes::process for this context's
+ * markers and phenotype t (src/bayes.cpp:375-553 -> dot_product, Gibbs step 396-492,
+ * update_epsilon 681-706) as ONE persistent kernel launch.
+ * ---------------------------------------------------------------------------------- */
+typedef struct gmrm_sweep_in {
+    int G, K;
+    const int*    order;       /* [M] shuffled local marker indices (Phenotype::midx)       */
+    const double* sigmag;      /* [G]                                                        */
+    const double* pi_est;      /* [G*K]                                                      */
+    const double* cva;         /* [G*K] mixture variances (Options::cva)                     */
+    double        sigmae;
+    uint32_t      rng_state[624];   /* Distributions dist_d: mt19937 state words ...          */
+    int           rng_index;        /* ... and position, 0..624                               */
+} gmrm_sweep_in;
+
+typedef struct gmrm_sweep_out {
+    int*     cass;             /* [G*K] component counts of this sweep (Phenotype::cass)     */
+    uint32_t rng_state[624];
+    int      rng_index;
+    long long n_updates;       /* visits with dbeta != 0                                     */
+    long long n_batches;       /* grid-wide synchronisation rounds                           */
+    double   device_ms;        /* kernel time, HIP events on the launch stream               */
+} gmrm_sweep_out;
+
+/* Per-marker group labels (Bayes::group_index restricted to [S, S+M)), shared by all t. */
+int gmrm_set_groups(gmrm_ctx* ctx, const int* group_local);
+int gmrm_sweep_launch(gmrm_ctx* ctx, int t, const gmrm_sweep_in* in);   /* asynchronous */
+int gmrm_sweep_finish(gmrm_ctx* ctx, int t, gmrm_sweep_out* out);       /* waits, collects */
+/* Per-marker chain state of phenotype t (Phenotype::betas / comp / acum). */
+int gmrm_get_betas(gmrm_ctx* ctx, int t, double* betas);
+int gmrm_get_comp(gmrm_ctx* ctx, int t, int* comp);
+int gmrm_get_acum(gmrm_ctx* ctx, int t, double* acum);
+int gmrm_set_betas(gmrm_ctx* ctx, int t, const double* betas);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-GPU residual exchange (replaces the per-step MPI_Allgatherv of src/bayes.cpp:
+ * 500-547 with one exchange per sweep; DESIGN.md "Multi-GPU").  The caller all-reduces
+ * (sum, f64) the 2*n4 doubles between the two calls, e.g. torch.distributed / RCCL on a
+ * tensor whose data_ptr() is `dev_q`.  n4 = 4*ceil(N/4).
+ * ---------------------------------------------------------------------------------- */
+int gmrm_eps_snapshot(gmrm_ctx* ctx, int t);                         /* eps_start = eps      */
+int gmrm_eps_delta_export(gmrm_ctx* ctx, int t, double* dev_q);      /* split2(eps-eps_start) */
+int gmrm_eps_delta_import(gmrm_ctx* ctx, int t, const double* dev_q);/* eps = start+(q1+q2)  */
+
+/* ------------------------------------------------------------------------------------
+ * Host-side sampler: Bayes::process() around the marker loop (src/bayes.cpp:318-371,
+ * 556-669) -- prologue draws, shuffle, hyper-parameter updates -- on the RNG spec of
+ * DESIGN.md, driving the context above.  One object per context, all T phenotypes.
+ * ---------------------------------------------------------------------------------- */
+typedef struct gmrm_sampler_opts {
+    uint32_t seed;             /* --seed                                                     */
+    int      rank, nranks;     /* marker-shard index / count (MPI rank / size upstream)      */
+    int      shuffle;          /* --shuffle-markers                                          */
+    int      mimic_hydra;      /* --mimic-hydra                                              */
+    int      G, K;
+    const double* cva;         /* [G*K] from --group-mixture-file                            */
+    const int*    group_index; /* [Mt]  from --group-index-file (all markers)                */
+} gmrm_sampler_opts;
+
+typedef struct gmrm_hyper {    /* one phenotype's state after an iteration                   */
+    double sigmae, mu;
+    int    m0_sum;
+    double sigmag[64];
+    double pi_est[64 * GMRM_KMAX];
+    long long n_updates, n_batches;
+    double sweep_device_ms;
+} gmrm_hyper;
+
+int gmrm_sampler_create(gmrm_sampler** out, gmrm_ctx* ctx, const gmrm_sampler_opts* opts);
+int gmrm_sampler_destroy(gmrm_sampler* s);
+int gmrm_sampler_init(gmrm_sampler* s);                                  /* bayes.cpp:322-335 */
+/* single shard (nranks == 1): one full iteration for every phenotype */
+int gmrm_sampler_iterate(gmrm_sampler* s, int it);
+/* sharded: the same iteration cut at its exchange points (see DESIGN.md "Multi-GPU") */
+int gmrm_sampler_draw_mu(gmrm_sampler* s, int it, double* mu_drawn /*[T]*/);
+int gmrm_sampler_begin_sweep(gmrm_sampler* s, const double* mu_use /*[T]*/);  /* launches  */
+int gmrm_sampler_end_sweep(gmrm_sampler* s, int* cass /*[T*G*K]*/, double* beta_sqn /*[T*G]*/);
+int gmrm_sampler_epilogue(gmrm_sampler* s, const int* cass, const double* beta_sqn);
+int gmrm_sampler_adopt(gmrm_sampler* s, int t, const double* sigmag, const double* pi_est, double sigmae);
+int gmrm_sampler_get(gmrm_sampler* s, int t, gmrm_hyper* out);
+/* one .csv record of phenotype t as write_ofile_csv formats it (src/xfiles.cpp:17-42) */
+int gmrm_sampler_csv_line(gmrm_sampler* s, int t, int it, char* buf, size_t len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,30 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_count():
+    try:
+        import gmrm_amd
+        return gmrm_amd.load_library().gmrm_device_count()
+    except Exception:
+        return 0
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """A HIP device must be present for -m gpu tests: no silent CPU fallback."""
+    n = _gpu_count()
+    if n < 1:
+        pytest.fail("gpu-marked test selected but libgmrm_hip sees no HIP device")
+    return n
