@@ -95,12 +95,33 @@ def library_path() -> Path:
     return Path(os.environ.get("GMRM_HIP_LIB", HERE / "libgmrm_hip.so"))
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7).  Two HIP
+    runtimes in one process cannot both own the GPU, and bench.py needs torch.distributed
+    (RCCL) beside this library, so when torch is installed its runtime is loaded first and
+    libgmrm_hip.so (NEEDED libamdhip64.so.7) binds to it.  GMRM_HIP_RUNTIME=system skips this."""
+    if os.environ.get("GMRM_HIP_RUNTIME", "torch") != "torch":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return None
+        cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+        if cand.exists():
+            return C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+    except Exception:
+        return None
+    return None
+
+
 def load_library():
     """Load libgmrm_hip.so; raises if it has not been built (no fallback)."""
     global _LIB
     if _LIB is not None:
         return _LIB
     path = library_path()
+    _share_torch_hip_runtime()
     if not path.exists():
         raise ImportError(f"{path} is missing: build it with `python -m gmrm_amd.build` "
                           "(hipcc --offload-arch=gfx950). gmrm_amd has no CPU fallback.")

@@ -230,7 +230,7 @@ __device__ __noinline__ void sample_batch(const SweepArgs& a, int nb, char* smem
             }
         }
     }
-    if (lane == s) {                                                 // s < nb here
+    if (s < nb && lane == s) {                                       // the stopping marker
         rs.cursor = cursor0 + prefix + 1;
         double beta_new = 0.0;
         if (kc > 0) beta_new = norm(rs, muk_c, a.sigmae / denom_c);  // bayes.cpp:455
