@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- SNP-updates/sec of the Gibbs sweep (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (default "c3"): 500 000 individuals x 1 000 000 SNPs, 1 phenotype, 1 group,
+synthetic genotypes generated on the device (copies ~ Binomial(2, 0.4), example/data_sim.R),
+phenotype y ~ N(0,1), seed 171014, mixtures 0 / 1e-4 / 1e-3 / 1e-2 (example/test.grm).
+Markers are block-partitioned over the N GPUs (the reference's own rule, bayes.cpp:903-925):
+total work is fixed, so scaling is "strong".  A step = one full Gibbs sweep (one iteration of
+Bayes::process: prologue draws, marker loop on every shard, residual exchange, hyper-parameter
+draws).  Genotypes, residual and all chain state are resident in HBM before the timed region.
+
+The JSON line carries, besides the driver's contract fields:
+  roofline     dominant kernel = the persistent sweep kernel; achieved = algorithmic bytes
+               (ceil(N/4) per SNP-update x markers per launch) / average launch duration
+               measured with HIP events on the launch stream inside this run.
+  cpu_baseline the oracle's reference-order OpenMP path (a port of the reference's own
+               vectorised loops, built -Ofast -march=native -fopenmp on this host) timed on
+               a bounded sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WORKLOADS = {
+    # name: (N individuals, Mt markers, T traits, G groups, phenotype-NA rate, genotype-missing rate)
+    "c2": (50_000, 100_000, 1, 1, 0.0, 0.0),
+    "c3": (500_000, 1_000_000, 1, 1, 0.0, 0.0),
+    "c4": (500_000, 1_000_000, 4, 1, 0.0, 0.0),
+    "c5": (500_000, 1_000_000, 1, 24, 0.05, 0.05),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+CPU_THREADS = 1
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--markers", type=int, default=0, help="override the total marker count (debug)")
+    ap.add_argument("--individuals", type=int, default=0, help="override N (debug)")
+    ap.add_argument("--seed", type=int, default=171014)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
+    return ap.parse_args()
+
+
+def cpu_baseline(ctx, eps, mask4, nonas, cva, seed, target_s):
+    """The reference-order OpenMP port on a bounded sample: the first `ms` markers of this
+    GPU's block (downloaded from the device), the same phenotype, 1 warm-up + timed sweeps."""
+    import numpy as np
+    from oracle import orc
+    threads = CPU_THREADS
+    orc.lib_fast_native()
+    N = ctx.N
+
+    def run(ms, sweeps):
+        bed = ctx.download_bed(0, ms)
+        ch = orc.Chain(N, bed, eps, mask4, nonas, np.zeros(ms, dtype=np.int32), cva, seed, canon=False, fast=True)
+        ch.iterate(1)                       # warm-up sweep (first touch, sigmae initialisation)
+        t0 = time.perf_counter()
+        for it in range(2, 2 + sweeps):
+            ch.iterate(it)
+        return (time.perf_counter() - t0) / sweeps
+
+    probe_ms = min(ctx.M, 256)
+    t_probe = run(probe_ms, 1)
+    per_marker = t_probe / probe_ms
+    ms = int(min(ctx.M, max(probe_ms, target_s / 3.0 / max(per_marker, 1e-9))))
+    ms = min(ms, 40_000)
+    t_sweep = run(ms, 2)
+    return {"value": ms / t_sweep, "unit": "SNP-updates/s", "cores": threads, "kind": "port",
+            "sample": f"first {ms} markers of the workload x 2 timed sweeps after 1 warm-up, N={N}, "
+                      f"reference-order loops (bayes.cpp:749-766, phenotype.cpp:375-390) with OpenMP, "
+                      f"-Ofast -march=native, OMP_NUM_THREADS={threads}"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    # CPU-baseline threads: the GPU box's CPU share for one GPU is 16 hardware threads; fixed
+    # here, before any OpenMP runtime starts (no OMP_PROC_BIND: it would pin this thread too).
+    global CPU_THREADS
+    CPU_THREADS = min(len(os.sched_getaffinity(0)), int(os.environ.get("GMRM_CPU_THREADS", "16")))
+    os.environ["OMP_NUM_THREADS"] = str(CPU_THREADS)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import gmrm_amd
+    from gmrm_amd.dist import HipEngine, ShardedDriver
+
+    lib = gmrm_amd.load_library()
+    if not torch.cuda.is_available() or lib.gmrm_device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    N, Mt, T, G, na_rate, miss = WORKLOADS[a.workload]
+    if a.markers:
+        Mt = a.markers
+    if a.individuals:
+        N = a.individuals
+    S, M, _ = gmrm_amd.block_of_markers(Mt, world, rank)
+
+    t_setup = time.perf_counter()
+    ctx = gmrm_amd.Context(N, M, Mt=Mt, S=S, T=T, device=local)
+    ctx.synth_bed(a.seed, 0.4, miss)
+    rng = np.random.default_rng(a.seed)
+    traits = []
+    for t in range(T):
+        y = rng.normal(size=N)
+        isna = (rng.random(N) < na_rate).astype(np.uint8) if na_rate > 0 else np.zeros(N, dtype=np.uint8)
+        eps, mask4, nonas = gmrm_amd.prepare_phenotype(y, isna)
+        ctx.upload_trait(t, eps, mask4, nonas)
+        traits.append((eps, mask4, nonas))
+    t_stats = time.perf_counter()
+    for t in range(T):
+        ctx.compute_markers_statistics(t)
+    t_stats = time.perf_counter() - t_stats
+    base = np.array([0.0, 0.0001, 0.001, 0.01])                 # example/test.grm
+    cva = np.tile(base, (G, 1))
+    group_index = (np.arange(Mt) % G).astype(np.int32)
+    smp = gmrm_amd.Sampler(ctx, a.seed, cva, group_index, rank=rank, nranks=world)
+    driver = ShardedDriver(HipEngine(smp, dev)) if world > 1 else None
+    t_setup = time.perf_counter() - t_setup
+
+    def step(it):
+        if driver is not None:
+            driver.iterate(it)
+        else:
+            smp.iterate(it)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        lib.gmrm_ctx_sync(ctx.h)
+
+    it = 0
+    for _ in range(a.warmup):
+        it += 1
+        step(it)
+    fence()
+    t0 = time.perf_counter()
+    kern_ms, upd, batches = [], [], []
+    for _ in range(a.steps):
+        it += 1
+        step(it)
+        hy = smp.hyper(0)
+        kern_ms.append(max(smp.hyper(t).sweep_device_ms for t in range(T)))
+        upd.append(hy.n_updates)
+        batches.append(hy.n_batches)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        mbytes = ctx.mbytes
+        value = Mt * T * a.steps / dt
+        avg_kernel_s = (sum(kern_ms) / len(kern_ms)) / 1e3
+        alg_bytes = float(M) * mbytes                          # ceil(N/4) bytes per SNP-update x markers per launch
+        achieved = alg_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        out = {
+            "metric": "SNP-updates/sec (Gibbs sweep)", "value": value, "unit": "SNP-updates/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {N} individuals x {Mt} SNPs, {T} phenotype(s), {G} group(s), "
+                                   f"K=4, genotypes Binomial(2,0.4) generated on device, y~N(0,1), seed {a.seed}",
+                       "markers_per_gpu": M, "parallelism": f"marker-shard x{world}, 1 residual all-reduce/sweep",
+                       "phenotype_na_rate": na_rate, "genotype_missing_rate": miss},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "gm::k_sweep (persistent marker loop)",
+                         "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "sweep": {"updates_per_sweep": upd, "sync_rounds_per_sweep": batches,
+                      "update_fraction": [u / float(M) for u in upd]},
+            "setup_s": t_setup, "marker_stats_s": t_stats,
+            "marker_stats_GBps": (M * ctx.mbytes * T) / t_stats / 1e9 if t_stats > 0 else None,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                eps, mask4, nonas = traits[0]
+                out["cpu_baseline"] = cpu_baseline(ctx, eps, mask4, nonas, cva[:1], a.seed, a.cpu_seconds)
+                out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            except Exception as e:                               # the baseline never blocks the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "SNP-updates/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    smp.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

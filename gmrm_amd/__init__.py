@@ -7,7 +7,7 @@ There is no CPU fallback: loading fails loudly when the library is missing, and 
 compute call fails when no HIP device is visible.
 """
 from ._lib import GmrmError, load_library, library_path  # noqa: F401
-from .api import Context, Sampler, Hyper, block_of_markers, im4_of  # noqa: F401
+from .api import Context, Sampler, Hyper, block_of_markers, im4_of, prepare_phenotype  # noqa: F401
 
 __all__ = ["GmrmError", "load_library", "library_path", "Context", "Sampler", "Hyper",
-           "block_of_markers", "im4_of"]
+           "block_of_markers", "im4_of", "prepare_phenotype"]

@@ -42,6 +42,20 @@ def _bp(a):
     return a.ctypes.data_as(c_u8_p)
 
 
+def prepare_phenotype(y, isna):
+    """Phenotype::read_file (src/phenotype.cpp:587-673) -> (eps[4*ceil(N/4)], mask4, nonas)."""
+    lib = _lib.load_library()
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    isna = np.ascontiguousarray(isna, dtype=np.uint8)
+    N = y.shape[0]
+    n4 = im4_of(N)
+    eps = np.zeros(4 * n4, dtype=np.float64)
+    mask4 = np.zeros(n4, dtype=np.uint8)
+    nonas = C.c_int(0)
+    check(lib.gmrm_phen_prepare(_dp(y), _bp(isna), N, _dp(eps), _bp(mask4), C.byref(nonas)))
+    return eps, mask4, nonas.value
+
+
 @dataclass
 class Hyper:
     sigmae: float

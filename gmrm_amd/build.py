@@ -36,10 +36,25 @@ def stale() -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
+def build(force: bool = False, verbose: bool = False, prof: bool = False) -> Path:
+    """prof=True builds the diagnostic variant libgmrm_hip_prof.so (-DGM_SWEEP_PROF: in-kernel
+    phase stamps); select it with GMRM_HIP_LIB=.../libgmrm_hip_prof.so GMRM_SWEEP_PROF=1."""
+    global LIB, FLAGS
+    if prof:
+        lib_prof = HERE / "libgmrm_hip_prof.so"
+        saved = (LIB, FLAGS)
+        LIB, FLAGS = lib_prof, FLAGS + ["-DGM_SWEEP_PROF"]
+        try:
+            return _build(True, verbose, "_build_prof")
+        finally:
+            LIB, FLAGS = saved
     if not force and not stale():
         return LIB
-    objdir = HERE / "_build"
+    return _build(force, verbose, "_build")
+
+
+def _build(force: bool, verbose: bool, objname: str) -> Path:
+    objdir = HERE / objname
     objdir.mkdir(exist_ok=True)
     objs = []
     procs = []
@@ -67,4 +82,4 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, prof="--prof" in sys.argv))

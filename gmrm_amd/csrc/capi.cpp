@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -100,7 +101,7 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
         HIPCHK(dalloc(&tr.rng_state, (size_t)624));
         HIPCHK(dalloc(&tr.rng_index, (size_t)4));
         HIPCHK(dalloc(&tr.cass, (size_t)GMAX * KMAX));
-        HIPCHK(dalloc(&tr.stats, (size_t)4));
+        HIPCHK(dalloc(&tr.stats, (size_t)20));
         HIPCHK(dalloc(&tr.err, (size_t)4));
         HIPCHK(dalloc(&tr.P, (size_t)SW_VMAX * c->Wpad));
         HIPCHK(dalloc(&tr.Tt, (size_t)SW_VMAX));
@@ -167,6 +168,32 @@ int gmrm_synth_bed(gmrm_ctx* c, uint64_t seed, double maf, double miss_rate) {
     HIPCHK(hipStreamSynchronize(c->tr[0].stream));
     c->have_bed = true;
     for (auto& tr : c->tr) tr.have_stats = false;
+    return GMRM_OK;
+}
+
+int gmrm_phen_prepare(const double* y, const uint8_t* isna, int N, double* epsilon, uint8_t* mask4, int* nonas_out) {
+    if (!y || !isna || !epsilon || !mask4 || !nonas_out || N < 2) return fail(GMRM_EINVAL, "bad argument");
+    const int im4 = (N % 4 == 0) ? N / 4 : N / 4 + 1;           // phenotype.cpp:22
+    int nonas = 0;
+    double sum = 0.0;
+    for (int i = 0; i < im4; i++) mask4[i] = 0x0F;               // phenotype.cpp:601
+    for (int i = 0; i < N; i++) {
+        if (isna[i]) mask4[i / 4] &= (uint8_t)~(1u << (i % 4));  // phenotype.cpp:614
+        else { nonas++; sum += y[i]; }
+    }
+    if (N % 4 != 0)                                              // phenotype.cpp:633-637
+        for (int i = N % 4; i < 4; i++) mask4[N / 4] &= (uint8_t)~(1u << i);
+    if (nonas < 2) return fail(GMRM_EINVAL, "fewer than two non-NA phenotype values");
+    const double avg = sum / (double)nonas;                      // phenotype.cpp:647-667
+    double sqn = 0.0;
+    for (int i = 0; i < N; i++) {
+        if (isna[i]) epsilon[i] = 0.0;
+        else { epsilon[i] = y[i] - avg; sqn += epsilon[i] * epsilon[i]; }
+    }
+    sqn = std::sqrt((double)(nonas - 1) / sqn);
+    for (int i = 0; i < N; i++) epsilon[i] *= sqn;
+    for (int i = N; i < 4 * im4; i++) epsilon[i] = 0.0;          // the reference leaves the tail uninitialised
+    *nonas_out = nonas;
     return GMRM_OK;
 }
 
@@ -372,7 +399,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     HIPCHK(hipMemcpyAsync(tr.rng_index, &in->rng_index, sizeof(int), hipMemcpyHostToDevice, tr.stream));
     HIPCHK(hipMemsetAsync(tr.cnt, 0, 96 * sizeof(unsigned), tr.stream));
     HIPCHK(hipMemsetAsync(tr.err, 0, 4 * sizeof(int), tr.stream));
-    HIPCHK(hipMemsetAsync(tr.stats, 0, 4 * sizeof(long long), tr.stream));
+    HIPCHK(hipMemsetAsync(tr.stats, 0, 20 * sizeof(long long), tr.stream));
 
     SweepArgs a{};
     a.N = c->N; a.M = c->M; a.W = c->W; a.Wpad = c->Wpad; a.G = G; a.K = K;
@@ -418,9 +445,18 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
     if (err[0] == 2) return fail(GMRM_EKERNEL, "sweep kernel: RNG window exhausted inside one batch");
     tr.cur ^= 1;
     if (out) {
-        long long st[4];
+        long long st[20];
         HIPCHK(hipMemcpy(st, tr.stats, sizeof(st), hipMemcpyDeviceToHost));
         out->n_updates = st[0]; out->n_batches = st[1];
+        if (std::getenv("GMRM_SWEEP_PROF")) {                  // diagnostic build only (-DGM_SWEEP_PROF)
+            static const char* nm[7] = {"prologue", "dots", "publish", "reduce", "wait_totals", "sample", "update"};
+            for (int w = 0; w < 2; w++) {
+                std::fprintf(stderr, "[sweep prof wg %s] batches %lld:", w ? "W/2" : "0", st[1]);
+                for (int i = 0; i < 7; i++)
+                    std::fprintf(stderr, " %s %.2fus", nm[i], st[1] ? st[(w ? 12 : 4) + i] * 0.01 / (double)st[1] : 0.0);
+                std::fprintf(stderr, "\n");
+            }
+        }
         if (out->cass) HIPCHK(hipMemcpy(out->cass, tr.cass, sizeof(int) * (size_t)tr.G * tr.K, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out->rng_state, tr.rng_state, 624 * sizeof(uint32_t), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(&out->rng_index, tr.rng_index, sizeof(int), hipMemcpyDeviceToHost));

@@ -283,6 +283,15 @@ __device__ __forceinline__ void load_words(const uint8_t* p, uint32_t (&w)[Slice
     else { const uint4 v = *reinterpret_cast<const uint4*>(p); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
 }
 
+// Diagnostic build only (-DGM_SWEEP_PROF): thread 0 of every workgroup accumulates wall-clock
+// ticks (100 MHz) per phase; workgroups 0 and W/2 write them to stats[4..]/stats[12..].
+#ifdef GM_SWEEP_PROF
+#define PROF(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+                                     prof[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define PROF(i) do { } while (0)
+#endif
+
 template <int R>
 __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -346,6 +355,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     int pos = 0;
     unsigned gen = 0, tgt2 = 0;
     long long n_upd = 0, n_batch = 0;
+#ifdef GM_SWEEP_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memrealtime();
+#endif
     int max_nb = 0;
     bool ok = true;
 
@@ -358,6 +371,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (tid < nb) s_m[tid] = a.order[pos + tid];
         __syncthreads();
 
+        PROF(0);   // batch prologue (MT advance, order fetch)
         // ---- phase A: partial dot products of the batch --------------------------------
         for (int g0 = 0; g0 < nb; g0 += SW_GB) {
             uint32_t wd[SW_GB][NW];
@@ -401,6 +415,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             if ((lane & 1) == 0) s_wsum[wave * SW_VMAX + g0 * 4 + (lane >> 1)] = acc[0];
         }
         __syncthreads();
+        PROF(1);   // phase A: dots
         const int nv = nb * 4;
         if (tid < nv) {
             const double tot = s_wsum[tid] + s_wsum[SW_VMAX + tid] + s_wsum[2 * SW_VMAX + tid] + s_wsum[3 * SW_VMAX + tid];
@@ -409,6 +424,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         drain_vm();
         __syncthreads();
         if (tid == 0) add_u32(cnt1, 1u);
+        PROF(2);   // publish partials + arrive
 
         // ---- reduce role: workgroup v sums row v over all workgroups ---------------------
         if (wg < nv) {
@@ -426,8 +442,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             drain_vm();
             if (tid == 0) add_u32(cnt2, 1u);
         }
+        PROF(3);   // reduce role (incl. waiting for all arrivals)
         tgt2 += (unsigned)(nv < W ? nv : W);
         if (!wait_ge(cnt2, tgt2, abort_word, ctl)) { ok = false; break; }
+        PROF(4);   // wait for the totals
 
         // ---- sampling step (wavefront 0, every workgroup, identical inputs) -------------
         if (wave == 0) {
@@ -442,6 +460,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             }
         }
         __syncthreads();
+        PROF(5);   // sampling step
         if (ctl[C_RNGERR]) { ok = false; break; }
 
         // ---- phase C: residual update of the stopping marker ----------------------------
@@ -463,6 +482,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         pos += ctl[C_NDONE];
         gen++;
         n_batch++;
+        PROF(6);   // residual update
     }
 
     if (!ok) {
@@ -486,6 +506,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             a.stats[0] = n_upd; a.stats[1] = n_batch; a.stats[2] = max_nb; a.stats[3] = 0;
         }
     }
+#ifdef GM_SWEEP_PROF
+    if (tid == 0 && (wg == 0 || wg == W / 2))
+        for (int i = 0; i < 8; i++) a.stats[(wg == 0 ? 4 : 12) + i] = (long long)prof[i];
+#endif
 }
 
 // Bytes per thread: the smallest R in {1,2,4,8,16} whose grid fits max_wg workgroups.

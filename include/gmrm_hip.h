@@ -66,6 +66,11 @@ int gmrm_download_bed(gmrm_ctx* ctx, uint8_t* cols, size_t first_marker, size_t 
  * copies of A1 ~ Binomial(2, maf) (example/data_sim.R:15), code 01 with prob. miss_rate. */
 int gmrm_synth_bed(gmrm_ctx* ctx, uint64_t seed, double maf, double miss_rate);
 
+/* Phenotype::read_file after tokenising (src/phenotype.cpp:587-673), host-only: y[N] values,
+ * isna[N] flags ("NA" tokens) -> eps[4*ceil(N/4)] centred and scaled to unit variance (0 at
+ * NA and in the tail), mask4[ceil(N/4)] (bit k = individual 4i+k present), *nonas. */
+int gmrm_phen_prepare(const double* y, const uint8_t* isna, int N, double* eps, uint8_t* mask4, int* nonas);
+
 /* Phenotype t: Phenotype ctor + read_file (src/phenotype.cpp:18-55,587-673): the centred,
  * scaled residual eps[4*ceil(N/4)] (0 at NA and in the tail), mask4[ceil(N/4)], nonas. */
 int gmrm_upload_trait(gmrm_ctx* ctx, int t, const double* eps, const uint8_t* mask4, int nonas);

@@ -22,12 +22,15 @@ class OrcRng(C.Structure):
     _fields_ = [("mt", C.c_uint32 * 624), ("idx", C.c_int)]
 
 
-def build(fast: bool = False, native: bool = False) -> Path:
-    """Compile the oracle with gcc (seconds).  `fast` = the timing build (-Ofast -fopenmp)."""
-    target = "liborc_fast.so" if fast else "liborc.so"
-    subprocess.run(["make", "-s", "-C", str(HERE), f"_build/{target}".replace("_build/", str(BUILD) + "/")],
-                   check=True)
-    return BUILD / target
+def _cpu_key() -> str:
+    """Identify this host's ISA so a -march=native build made elsewhere is never loaded."""
+    import hashlib
+    try:
+        txt = Path("/proc/cpuinfo").read_text()
+        flags = next(ln for ln in txt.splitlines() if ln.startswith("flags"))
+    except Exception:
+        flags = "unknown"
+    return hashlib.sha1(flags.encode()).hexdigest()[:10]
 
 
 def _dp(a):
@@ -107,14 +110,22 @@ _libs = {}
 
 
 def lib(fast: bool = False):
-    """Load (building if needed) the strict oracle, or the -Ofast/OpenMP timing build."""
+    """Load (building if needed) the strict oracle -- the parity checker -- or, with
+    fast=True, the timing build: the reference's flags (-Ofast -march=native -fopenmp,
+    setup/Make.gcc_mvapich2:15-16) compiled for THIS host."""
     key = "fast" if fast else "strict"
     if key in _libs:
         return _libs[key]
-    path = BUILD / ("liborc_fast.so" if fast else "liborc.so")
     src = HERE / "gmrm_oracle.c"
+    BUILD.mkdir(exist_ok=True)
+    if fast:
+        path = BUILD / f"liborc_fast_{_cpu_key()}.so"
+        flags = ["-Ofast", "-fPIC", "-std=c11", "-fopenmp", "-march=native"]
+    else:
+        path = BUILD / "liborc.so"
+        flags = ["-O2", "-fPIC", "-std=c11", "-mfma", "-ffp-contract=off", "-fno-fast-math"]
     if not path.exists() or path.stat().st_mtime < src.stat().st_mtime:
-        subprocess.run(["make", "-s", "-C", str(HERE), str(path)], check=True)
+        subprocess.run(["gcc", *flags, "-shared", "-o", str(path), str(src), "-lm"], check=True)
     L = C.CDLL(str(path))
     for name, (res, args) in _SIGS.items():
         fn = getattr(L, name)
@@ -122,6 +133,10 @@ def lib(fast: bool = False):
         fn.argtypes = args
     _libs[key] = L
     return L
+
+
+def lib_fast_native():
+    return lib(fast=True)
 
 
 def im4_of(N: int) -> int:
