@@ -103,8 +103,8 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
         HIPCHK(dalloc(&tr.cass, (size_t)GMAX * KMAX));
         HIPCHK(dalloc(&tr.stats, (size_t)20));
         HIPCHK(dalloc(&tr.err, (size_t)4));
-        HIPCHK(dalloc(&tr.P, (size_t)SW_VMAX * c->Wpad));
-        HIPCHK(dalloc(&tr.Tt, (size_t)SW_VMAX));
+        HIPCHK(dalloc(&tr.P, (size_t)2 * SW_VMAX * c->Wpad));       // two 8-byte granules per value
+        HIPCHK(dalloc(&tr.Tt, (size_t)2 * SW_VMAX));
         HIPCHK(dalloc(&tr.cnt, (size_t)96));
         HIPCHK(dalloc(&tr.scratch, (size_t)8));
         HIPCHK(hipStreamCreateWithFlags(&tr.stream, hipStreamNonBlocking));
@@ -397,7 +397,10 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     HIPCHK(hipMemcpyAsync(tr.order, in->order, (size_t)c->M * sizeof(int), hipMemcpyHostToDevice, tr.stream));
     HIPCHK(hipMemcpyAsync(tr.rng_state, in->rng_state, 624 * sizeof(uint32_t), hipMemcpyHostToDevice, tr.stream));
     HIPCHK(hipMemcpyAsync(tr.rng_index, &in->rng_index, sizeof(int), hipMemcpyHostToDevice, tr.stream));
+    // every polled word starts at zero in every launch (tags count from 1 inside the launch)
     HIPCHK(hipMemsetAsync(tr.cnt, 0, 96 * sizeof(unsigned), tr.stream));
+    HIPCHK(hipMemsetAsync(tr.P, 0, (size_t)2 * SW_VMAX * c->Wpad * sizeof(double), tr.stream));
+    HIPCHK(hipMemsetAsync(tr.Tt, 0, (size_t)2 * SW_VMAX * sizeof(double), tr.stream));
     HIPCHK(hipMemsetAsync(tr.err, 0, 4 * sizeof(int), tr.stream));
     HIPCHK(hipMemsetAsync(tr.stats, 0, 20 * sizeof(long long), tr.stream));
 

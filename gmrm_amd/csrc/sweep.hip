@@ -18,13 +18,20 @@
 // the batch is then stale.  The residual update is applied and the next batch starts after
 // that marker.  Results are exactly those of the one-marker-at-a-time loop.
 //
-// Exchange per batch (placement-independent, gfx950: private L2 per XCD):
-//   1. every workgroup stores its nb*4 partials to P[v][wg] with sc1 (write-through) stores,
-//      drains them, then one lane bumps cnt1 (agent-scope atomic);
-//   2. workgroup v (v < nb*4) waits for cnt1, reads row v with sc1 loads, reduces it, stores
-//      the total Tt[v] (sc1), bumps cnt2;
-//   3. every workgroup waits for cnt2, reads the totals (sc1 loads) and runs the SAME sampling
-//      step on the SAME RNG stream (kept in LDS) -- redundant, hence no broadcast hop.
+// Genotype stream.  The visit order is known for the whole sweep, so each workgroup keeps a
+// 128-position ring of its 256*R-byte column slices in LDS.  Wavefronts 1-2 fetch the slices
+// of upcoming positions (coalesced 2R-byte loads, NA mask applied once) while wavefront 0 is
+// busy with the exchange; phase A and the residual update read the ring, never HBM.
+//
+// Exchange per batch (placement-independent, gfx950: private L2 per XCD).  "The data is the
+// flag": every exchanged double travels as two 8-byte granules {tag = batch number + 1,
+// 32 data bits}, each written by ONE sc1 (write-through) store and read by sc1 loads until
+// the tag matches -- no counters, no fences.
+//   1. every workgroup stores its nb*4 partial sums to P[v][wg];
+//   2. workgroup v (v < nb*4) polls row v, reduces it (exact sums: any order), stores the
+//      total Tt[v];
+//   3. wavefront 0 of EVERY workgroup polls the totals and runs the SAME sampling step on the
+//      SAME RNG stream (kept in LDS) -- redundant, hence no broadcast hop.
 // Every spin is bounded (wall-clock timeout -> error word -> all workgroups leave).
 #include "gm_common.h"
 #include "gm_rng.h"
@@ -33,40 +40,67 @@
 namespace gm {
 
 // ---- LDS carve (bytes, all multiples of 16) --------------------------------------------
+constexpr int RING_POS = 128;                   // ring capacity in order positions (2 * SW_BMAX)
+constexpr int PFN      = 24;                    // positions prefetched per batch per loader thread
 constexpr int L_LUT  = 0;                       // double2[4]   (a,b) per 2-bit code
 constexpr int L_VAL  = 64;                      // double[4]    update table of the stopping marker
 constexpr int L_CTL  = 96;                      // int[16]      control words
-constexpr int L_M    = 160;                     // int[64]      marker ids of the batch
+constexpr int L_M    = 160;                     // int[64]      (spare)
 constexpr int L_RNG0 = 416;                     // uint32[624]  current MT block (untempered)
 constexpr int L_RNG1 = L_RNG0 + 2496;           // uint32[624]  next MT block
 constexpr int L_CASS = L_RNG1 + 2496;           // int[GMAX*KMAX]
 constexpr int L_WSUM = L_CASS + GMAX * KMAX * 4;   // double[4][SW_VMAX]
 constexpr int L_RED  = L_WSUM + 4 * SW_VMAX * 8;   // double[4]
-constexpr int L_END  = L_RED + 64;
-// Request > 80 KiB so that exactly one workgroup fits per CU (the hand-off forms used here
-// are the ones measured at one workgroup per CU).
-constexpr int L_TOTAL = 84 * 1024;
-static_assert(L_END <= L_TOTAL, "LDS carve");
+constexpr int L_TAB  = L_RED + 64;                 // double[GMAX*(1+3*KMAX)] per-group tables
+constexpr int L_RING = L_TAB + GMAX * (1 + 3 * KMAX) * 8;   // uint8[RING_POS][SW_TPB*R]
+static_assert(L_RING % 16 == 0, "LDS carve");
+// Request > 80 KiB so that exactly one workgroup fits per CU.
+constexpr int L_MIN = 84 * 1024;
+constexpr int lds_total(int R) { return (L_RING + RING_POS * SW_TPB * R) > L_MIN ? (L_RING + RING_POS * SW_TPB * R) : L_MIN; }
+static_assert(lds_total(4) <= 160 * 1024, "LDS budget");
 
-enum { C_NDONE = 0, C_UPD, C_MUPD, C_NBNEXT, C_CURSOR, C_OK, C_EMA, C_RNGERR };
+enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR };
 
-size_t sweep_lds_bytes() { return L_TOTAL; }
+size_t sweep_lds_bytes() { return (size_t)lds_total(4); }
 
 // Every word another workgroup reads or writes inside the launch is accessed through a
 // GLOBAL (address space 1) agent-scope atomic: global_load/store ... sc1, never flat_.
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define GM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-__device__ __forceinline__ void st_sc1(double* p, double v) {
-    __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), GM_RLX_AGENT);
-}
-__device__ __forceinline__ double ld_sc1(const double* p) {
-    return __longlong_as_double((long long)__hip_atomic_load((const gu64*)p, GM_RLX_AGENT));
-}
+__device__ __forceinline__ unsigned long long ld_g(const unsigned long long* p) { return __hip_atomic_load((const gu64*)p, GM_RLX_AGENT); }
+__device__ __forceinline__ void st_g(unsigned long long* p, unsigned long long v) { __hip_atomic_store((gu64*)p, v, GM_RLX_AGENT); }
 __device__ __forceinline__ unsigned ld_u32(const unsigned* p) { return __hip_atomic_load((const gu32*)p, GM_RLX_AGENT); }
 __device__ __forceinline__ void st_u32(unsigned* p, unsigned v) { __hip_atomic_store((gu32*)p, v, GM_RLX_AGENT); }
-__device__ __forceinline__ void add_u32(unsigned* p, unsigned v) { __hip_atomic_fetch_add((gu32*)p, v, GM_RLX_AGENT); }
-__device__ __forceinline__ void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// one double as two tagged granules
+__device__ __forceinline__ void put_value(unsigned long long* g, unsigned tag, double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    st_g(g, ((unsigned long long)tag << 32) | (u & 0xffffffffull));
+    st_g(g + 1, ((unsigned long long)tag << 32) | (u >> 32));
+}
+__device__ __forceinline__ bool get_value(const unsigned long long* g, unsigned tag, double& v) {
+    const unsigned long long g0 = ld_g(g), g1 = ld_g(g + 1);
+    v = __longlong_as_double((long long)((g0 & 0xffffffffull) | (g1 << 32)));
+    return (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
+}
+
+// Spin budget shared by every poll loop: give up after ~4 s of wall clock or when another
+// workgroup has raised the abort word.
+struct Spin {
+    unsigned long long t0;
+    unsigned n;
+    __device__ __forceinline__ void start() { t0 = __builtin_amdgcn_s_memrealtime(); n = 0; }
+    __device__ __forceinline__ bool expired(unsigned* abort_word) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++n & 63u) != 0u) return false;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull || ld_u32(abort_word) != 0u) {
+            st_u32(abort_word, 1u);
+            return true;
+        }
+        return false;
+    }
+};
 
 // The MT stream as the sampling wavefront sees it: two consecutive 624-word blocks in LDS.
 struct LdsStream {
@@ -103,37 +137,12 @@ __device__ void block_advance(uint32_t* s0, uint32_t* s1, int* ctl, bool copy) {
     __syncthreads();
 }
 
-// Bounded wait until *p >= target (monotonic counter).  All threads call; returns false on
-// timeout or if another workgroup raised the abort word.
-__device__ bool wait_ge(unsigned* p, unsigned target, unsigned* abort_word, int* ctl) {
-    __syncthreads();                                  // readers of the previous verdict are done
-    if (threadIdx.x == 0) {
-        bool ok = true;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        unsigned spins = 0;
-        while (ld_u32(p) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 127u) == 0u) {
-                const bool late = __builtin_amdgcn_s_memrealtime() - t0 > 400000000ull;   // 4 s @ 100 MHz
-                if (late || ld_u32(abort_word) != 0u) {
-                    st_u32(abort_word, 1u);
-                    ok = false;
-                    break;
-                }
-            }
-        }
-        ctl[C_OK] = ok ? 1 : 0;
-    }
-    __syncthreads();
-    return ctl[C_OK] != 0;
-}
-
 // bayes.cpp:403-477 for one marker, given num (the dot product + beta*(nonas-1)) and the
 // uniform draw: returns the chosen component, the acum value and muk/denom of that component.
 template <int K>
-__device__ __forceinline__ void decide(double num, double prob, const double* __restrict__ denom_g,
-                                       const double* __restrict__ logpi_g, const double* __restrict__ mhl_g,
-                                       double inv2sige, int& kc, double& acum_v, double& muk_c, double& denom_c) {
+__device__ __forceinline__ void decide(double num, double prob, const double* denom_g, const double* logpi_g,
+                                       const double* mhl_g, double inv2sige, int& kc, double& acum_v,
+                                       double& muk_c, double& denom_c) {
     double muk[K], logl[K];
     muk[0] = 0.0;
     logl[0] = logpi_g[0];
@@ -181,39 +190,71 @@ __device__ __forceinline__ void decide(double num, double prob, const double* __
         if (i == kc) { muk_c = muk[i]; denom_c = denom_g[i]; }
 }
 
+// What lane j of the sampling wavefront needs about batch position j; fetched at batch
+// start (these loads do not depend on the dots) so they are in registers when the totals land.
+struct LaneIn {
+    int m, g;
+    double beta_old, mave, msig;
+};
+struct SampleOut {                 // global outputs, written by workgroup 0 only
+    double* acum;
+    double* betas_out;
+    int* comp;
+};
+
 // The Gibbs step for a whole batch, run by wavefront 0 of EVERY workgroup on identical
 // inputs.  Lane j handles batch position j; the walk stops at the first lane whose effect
-// may change.  Only workgroup 0 writes per-marker outputs.
+// may change.  Returns false on a poll timeout.
 template <int K>
-__device__ __noinline__ void sample_batch(const SweepArgs& a, int nb, char* smem, bool writer) {
+__device__ __noinline__ bool sample_batch(int nb, int G, char* smem, const LaneIn in, const unsigned long long* Ttg,
+                                          unsigned tag, double sigmae, double inv2sige, double nm1,
+                                          const SampleOut out, bool writer, unsigned* abort_word) {
     const int lane = threadIdx.x & 63;
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
-    const int* s_m = reinterpret_cast<const int*>(smem + L_M);
     double* s_val = reinterpret_cast<double*>(smem + L_VAL);
     int* s_cass = reinterpret_cast<int*>(smem + L_CASS);
+    const double* tab = reinterpret_cast<const double*>(smem + L_TAB);
     LdsStream rs{reinterpret_cast<const uint32_t*>(smem + L_RNG0), reinterpret_cast<const uint32_t*>(smem + L_RNG1),
                  ctl[C_CURSOR], &ctl[C_RNGERR]};
 
     const bool act = lane < nb;
-    const int m = act ? s_m[lane] : 0;
-    const int g = act ? a.group[m] : 0;
-    const double beta_old = act ? a.betas_in[m] : 0.0;
-    const bool sig0 = act && (a.sigmag[g] == 0.0);              // bayes.cpp:396-400
+    const int m = in.m, g = in.g;
+    const double beta_old = in.beta_old;
+    const bool sig0 = act && (tab[g] == 0.0);                   // bayes.cpp:396-400
     const bool use = act && !sig0;
     const unsigned long long use_mask = __ballot(use);
     const int prefix = __popcll(use_mask & ((1ull << lane) - 1ull));
     const int cursor0 = rs.cursor;
     const double prob = unif_from_word(rs.peek(cursor0 + prefix));   // bayes.cpp:435
 
+    // the four totals of this lane's marker (tagged granules, polled until they arrive)
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    {
+        Spin sp;
+        sp.start();
+        bool bad = false;
+        for (;;) {
+            bool ok = true;
+            if (use) {
+                ok &= get_value(Ttg + 2 * (4 * lane + 0), tag, t0);
+                ok &= get_value(Ttg + 2 * (4 * lane + 1), tag, t1);
+                ok &= get_value(Ttg + 2 * (4 * lane + 2), tag, t2);
+                ok &= get_value(Ttg + 2 * (4 * lane + 3), tag, t3);
+            }
+            if (__all(ok)) break;
+            if (sp.expired(abort_word)) { bad = true; break; }
+        }
+        if (__any(bad)) return false;
+    }
+
     int kc = 0;
     double acum_v = 1.0, muk_c = 0.0, denom_c = 1.0;
     if (use) {
-        const double t0 = ld_sc1(&a.Tt[4 * lane + 0]), t1 = ld_sc1(&a.Tt[4 * lane + 1]);
-        const double t2 = ld_sc1(&a.Tt[4 * lane + 2]), t3 = ld_sc1(&a.Tt[4 * lane + 3]);
         const double dpa = t0 + t1, dpb = t2 + t3;
-        double num = a.msig[m] * (dpa - a.mave[m] * dpb);           // bayes.cpp:765
-        num += beta_old * a.nm1;                                     // bayes.cpp:421
-        decide<K>(num, prob, a.denom + g * K, a.logpi + g * K, a.mhl + g * K, a.inv2sige, kc, acum_v, muk_c, denom_c);
+        double num = in.msig * (dpa - in.mave * dpb);               // bayes.cpp:765
+        num += beta_old * nm1;                                       // bayes.cpp:421
+        decide<K>(num, prob, tab + G + g * K, tab + G + G * K + g * K, tab + G + 2 * G * K + g * K, inv2sige,
+                  kc, acum_v, muk_c, denom_c);
     }
     const bool stop = use && (kc > 0 || beta_old != 0.0);
     const unsigned long long stop_mask = __ballot(stop);
@@ -222,35 +263,33 @@ __device__ __noinline__ void sample_batch(const SweepArgs& a, int nb, char* smem
 
     if (act && lane < n_done && lane != s) {
         if (sig0) {
-            if (writer) { a.acum[m] = 1.0; a.betas_out[m] = 0.0; }
-        } else {                                                     // component 0, effect stays 0
-            if (writer) {
-                a.acum[m] = acum_v; a.betas_out[m] = 0.0; a.comp[m] = 0;
-                atomicAdd(&s_cass[g * K + 0], 1);
-            }
+            if (writer) { out.acum[m] = 1.0; out.betas_out[m] = 0.0; }
+        } else if (writer) {                                         // component 0, effect stays 0
+            out.acum[m] = acum_v; out.betas_out[m] = 0.0; out.comp[m] = 0;
+            atomicAdd(&s_cass[g * K + 0], 1);
         }
     }
     if (s < nb && lane == s) {                                       // the stopping marker
         rs.cursor = cursor0 + prefix + 1;
         double beta_new = 0.0;
-        if (kc > 0) beta_new = norm(rs, muk_c, a.sigmae / denom_c);  // bayes.cpp:455
+        if (kc > 0) beta_new = norm(rs, muk_c, sigmae / denom_c);    // bayes.cpp:455
         const double dbeta = beta_old - beta_new;                    // bayes.cpp:479
         int upd = 0;
         if (fabs(dbeta) > 0.0) {                                     // bayes.cpp:483, phenotype.cpp:328-329,388
             upd = 1;
-            const double bs_ = dbeta * a.msig[m];
-            const double mdb = -a.mave[m];
+            const double bs_ = dbeta * in.msig;
+            const double mdb = -in.mave;
             s_val[0] = (mdb * 1.0 + 2.0) * bs_;
             s_val[1] = (mdb * 0.0 + 0.0) * bs_;
             s_val[2] = (mdb * 1.0 + 1.0) * bs_;
             s_val[3] = (mdb * 1.0 + 0.0) * bs_;
-            ctl[C_MUPD] = m;
         }
         if (writer) {
-            a.acum[m] = acum_v; a.betas_out[m] = beta_new; a.comp[m] = kc;
+            out.acum[m] = acum_v; out.betas_out[m] = beta_new; out.comp[m] = kc;
             atomicAdd(&s_cass[g * K + kc], 1);
         }
         ctl[C_UPD] = upd;
+        ctl[C_SUPD] = s;
         ctl[C_CURSOR] = rs.cursor;
         ctl[C_NDONE] = n_done;
     }
@@ -267,21 +306,14 @@ __device__ __noinline__ void sample_batch(const SweepArgs& a, int nb, char* smem
         nxt = nxt < SW_GB ? SW_GB : (nxt > SW_BMAX ? SW_BMAX : nxt);
         ctl[C_NBNEXT] = nxt;
     }
+    return true;
 }
 
-template <int R> struct Slice {
-    static constexpr int NI = 4 * R;                 // individuals per thread
-    static constexpr int NW = R >= 4 ? R / 4 : 1;    // 32-bit words per thread per column
-};
-
-template <int R>
-__device__ __forceinline__ void load_words(const uint8_t* p, uint32_t (&w)[Slice<R>::NW]) {
-    if constexpr (R == 1) w[0] = *p;
-    else if constexpr (R == 2) w[0] = *reinterpret_cast<const uint16_t*>(p);
-    else if constexpr (R == 4) w[0] = *reinterpret_cast<const uint32_t*>(p);
-    else if constexpr (R == 8) { const uint2 v = *reinterpret_cast<const uint2*>(p); w[0] = v.x; w[1] = v.y; }
-    else { const uint4 v = *reinterpret_cast<const uint4*>(p); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-}
+// ---- per-R storage types ------------------------------------------------------------------
+template <int R> struct Slice;
+template <> struct Slice<1> { using own_t = uint8_t;  using ld_t = uint16_t; };
+template <> struct Slice<2> { using own_t = uint16_t; using ld_t = uint32_t; };
+template <> struct Slice<4> { using own_t = uint32_t; using ld_t = unsigned long long; };
 
 // Diagnostic build only (-DGM_SWEEP_PROF): thread 0 of every workgroup accumulates wall-clock
 // ticks (100 MHz) per phase; workgroups 0 and W/2 write them to stats[4..]/stats[12..].
@@ -295,33 +327,36 @@ __device__ __forceinline__ void load_words(const uint8_t* p, uint32_t (&w)[Slice
 template <int R>
 __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NI = Slice<R>::NI, NW = Slice<R>::NW;
-    constexpr int IPW = NI / NW;                     // individuals per word (<= 16)
+    using own_t = typename Slice<R>::own_t;          // this thread's R bytes of a column
+    using ld_t = typename Slice<R>::ld_t;            // a loader thread's 2R bytes
+    constexpr int NI = 4 * R;                        // individuals per thread
+    constexpr ld_t ODD = (ld_t)0x5555555555555555ull;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
-    const int W = a.W, K = a.K;
+    const int W = a.W, K = a.K, G = a.G;
 
     double2* lut = reinterpret_cast<double2*>(smem + L_LUT);
     const double* s_val = reinterpret_cast<const double*>(smem + L_VAL);
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
-    int* s_m = reinterpret_cast<int*>(smem + L_M);
     uint32_t* s_rng0 = reinterpret_cast<uint32_t*>(smem + L_RNG0);
     uint32_t* s_rng1 = reinterpret_cast<uint32_t*>(smem + L_RNG1);
     int* s_cass = reinterpret_cast<int*>(smem + L_CASS);
     double* s_wsum = reinterpret_cast<double*>(smem + L_WSUM);
     double* s_red = reinterpret_cast<double*>(smem + L_RED);
-    unsigned* cnt1 = a.cnt;
-    unsigned* cnt2 = a.cnt + 32;
+    double* s_tab = reinterpret_cast<double*>(smem + L_TAB);
+    char* ring = smem + L_RING;
     unsigned* abort_word = a.cnt + 64;
+    unsigned long long* Pg = reinterpret_cast<unsigned long long*>(a.P);
+    unsigned long long* Ttg = reinterpret_cast<unsigned long long*>(a.Tt);
 
     if (tid < 4) lut[tid] = make_double2(code_a(tid), code_b(tid));
     for (int i = tid; i < 624; i += SW_TPB) s_rng0[i] = a.rng_state[i];
-    for (int i = tid; i < a.G * K; i += SW_TPB) s_cass[i] = 0;
+    for (int i = tid; i < G * K; i += SW_TPB) s_cass[i] = 0;
+    for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];   // sigmag|denom|logpi|mhl, contiguous
     if (tid == 0) {
         ctl[C_CURSOR] = *a.rng_index;
         ctl[C_RNGERR] = 0;
         ctl[C_EMA] = 16 * a.batch_init / 2;
         ctl[C_NBNEXT] = a.batch_init;
-        ctl[C_OK] = 1;
     }
     __syncthreads();
     block_advance(s_rng0, s_rng1, ctl, false);       // S1 = twist(S0)
@@ -330,71 +365,97 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     const size_t b0 = ((size_t)wg * SW_TPB + tid) * R;
     const bool valid = b0 < a.stride;
     double eps[NI], q1[NI], q2[NI];
-    uint32_t nam[NW];
     if (valid) {
-        load_words<R>(a.namask2 + b0, nam);
 #pragma unroll
         for (int i = 0; i < NI; i++) eps[i] = a.eps[4 * b0 + i];
     } else {
-#pragma unroll
-        for (int w = 0; w < NW; w++) nam[w] = 0u;
 #pragma unroll
         for (int i = 0; i < NI; i++) eps[i] = 0.0;
     }
 #pragma unroll
     for (int i = 0; i < NI; i++) split2(eps[i], q1[i], q2[i]);
+
+    // ---- loader role (wavefronts 1-2): 2R bytes of every upcoming column ----------------
     // codes of NA / out-of-range individuals are forced to 01 (a = b = 0, update value 0)
-    uint32_t keep[NW], force[NW];
-#pragma unroll
-    for (int w = 0; w < NW; w++) { keep[w] = nam[w]; force[w] = ~nam[w] & 0x55555555u; }
-    if constexpr (R < 4) {                           // unused high fields of the single word
-        constexpr uint32_t used = (R == 1) ? 0xFFu : 0xFFFFu;
-        keep[0] &= used; force[0] = (~nam[0] & 0x55555555u & used);
+    const bool loader = wave == 1 || wave == 2;
+    const int lt = loader ? tid - 64 : 0;
+    const size_t cb = (size_t)wg * SW_TPB * R + (size_t)lt * 2 * R;
+    const bool lvalid = loader && cb < a.stride;
+    ld_t lkeep = 0, lforce = ODD;
+    if (lvalid) {
+        const ld_t nam = *reinterpret_cast<const ld_t*>(a.namask2 + cb);
+        lkeep = nam;
+        lforce = (ld_t)(~nam) & ODD;
     }
+    ld_t pf[PFN];
+    int hi = 0;                                       // ring holds order positions [pos, hi)
+
+    // synchronous ring fill of positions [from, to) (start-up and the rare slow path)
+    auto fill = [&](int from, int to) {
+        for (int p0 = from; p0 < to; p0 += PFN) {
+            const int n = (to - p0) < PFN ? (to - p0) : PFN;
+            if (loader) {
+#pragma unroll
+                for (int i = 0; i < PFN; i++) {
+                    ld_t w = ODD;
+                    if (i < n && lvalid) w = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[p0 + i] * a.stride + cb);
+                    pf[i] = (w & lkeep) | lforce;
+                }
+#pragma unroll
+                for (int i = 0; i < PFN; i++)
+                    if (i < n) *reinterpret_cast<ld_t*>(ring + (size_t)((p0 + i) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)lt * 2 * R) = pf[i];
+            }
+        }
+        __syncthreads();
+    };
 
     int pos = 0;
-    unsigned gen = 0, tgt2 = 0;
+    unsigned gen = 0;
     long long n_upd = 0, n_batch = 0;
+    int max_nb = 0;
+    bool ok = true;
 #ifdef GM_SWEEP_PROF
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memrealtime();
 #endif
-    int max_nb = 0;
-    bool ok = true;
+    {
+        const int first = a.batch_init + SW_BMAX < a.M ? a.batch_init + SW_BMAX : a.M;
+        fill(0, first);
+        hi = first;
+    }
 
     while (pos < a.M) {
         if (ctl[C_CURSOR] >= 624) block_advance(s_rng0, s_rng1, ctl, true);
         int nb = ctl[C_NBNEXT];
         if (nb > a.M - pos) nb = a.M - pos;
         max_nb = nb > max_nb ? nb : max_nb;
-        __syncthreads();
-        if (tid < nb) s_m[tid] = a.order[pos + tid];
-        __syncthreads();
+        if (hi < pos + nb) { fill(hi, pos + nb); hi = pos + nb; }    // slow path (uniform)
+        const unsigned tag = gen + 1u;
 
-        PROF(0);   // batch prologue (MT advance, order fetch)
-        // ---- phase A: partial dot products of the batch --------------------------------
+        // wavefront 0: what the sampling step needs about each batch position (overlaps phase A)
+        LaneIn li{0, 0, 0.0, 0.0, 1.0};
+        if (wave == 0 && lane < nb) {
+            li.m = a.order[pos + lane];
+            li.g = a.group[li.m];
+            li.beta_old = a.betas_in[li.m];
+            li.mave = a.mave[li.m];
+            li.msig = a.msig[li.m];
+        }
+        __syncthreads();                              // ring writes of the previous batch are visible
+        PROF(0);   // batch prologue
+
+        // ---- phase A: partial dot products of the batch, genotypes from the ring ----------
         for (int g0 = 0; g0 < nb; g0 += SW_GB) {
-            uint32_t wd[SW_GB][NW];
-#pragma unroll
-            for (int gm = 0; gm < SW_GB; gm++) {
-                const int j = g0 + gm;
-                if (valid && j < nb) {
-                    load_words<R>(a.bed + (size_t)s_m[j] * a.stride + b0, wd[gm]);
-#pragma unroll
-                    for (int w = 0; w < NW; w++) wd[gm][w] = (wd[gm][w] & keep[w]) | force[w];
-                } else {
-#pragma unroll
-                    for (int w = 0; w < NW; w++) wd[gm][w] = 0x55555555u;
-                }
-            }
             double acc[SW_GB * 4];
 #pragma unroll
             for (int gm = 0; gm < SW_GB; gm++) {
+                const int j = g0 + gm;
+                uint32_t wd = 0x55555555u;
+                if (j < nb) wd = *reinterpret_cast<const own_t*>(ring + (size_t)((pos + j) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)tid * R);
                 double sa1 = 0.0, sa2 = 0.0, sb1 = 0.0, sb2 = 0.0;
 #pragma unroll
                 for (int i = 0; i < NI; i++) {
-                    const uint32_t c = (wd[gm][i / IPW] >> (2 * (i % IPW))) & 3u;
-                    const double2 ab = lut[c];
+                    const double2 ab = lut[(wd >> (2 * i)) & 3u];
                     sa1 = fma_(ab.x, q1[i], sa1); sa2 = fma_(ab.x, q2[i], sa2);
                     sb1 = fma_(ab.y, q1[i], sb1); sb2 = fma_(ab.y, q2[i], sb2);
                 }
@@ -419,70 +480,87 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         const int nv = nb * 4;
         if (tid < nv) {
             const double tot = s_wsum[tid] + s_wsum[SW_VMAX + tid] + s_wsum[2 * SW_VMAX + tid] + s_wsum[3 * SW_VMAX + tid];
-            st_sc1(&a.P[(size_t)tid * a.Wpad + wg], tot);
+            put_value(Pg + 2 * ((size_t)tid * a.Wpad + wg), tag, tot);
         }
-        drain_vm();
-        __syncthreads();
-        if (tid == 0) add_u32(cnt1, 1u);
-        PROF(2);   // publish partials + arrive
+        PROF(2);   // publish partials
 
         // ---- reduce role: workgroup v sums row v over all workgroups ---------------------
+        bool bad = false;
         if (wg < nv) {
-            if (!wait_ge(cnt1, (unsigned)W * (gen + 1u), abort_word, ctl)) { ok = false; break; }
             for (int v = wg; v < nv; v += W) {
                 double x = 0.0;
-                for (int w = tid; w < W; w += SW_TPB) x += ld_sc1(&a.P[(size_t)v * a.Wpad + w]);
+                if (tid < W) {
+                    Spin sp;
+                    sp.start();
+                    const unsigned long long* gp = Pg + 2 * ((size_t)v * a.Wpad + tid);
+                    while (!get_value(gp, tag, x)) {
+                        if (sp.expired(abort_word)) { bad = true; x = 0.0; break; }
+                    }
+                }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
                 if (lane == 0) s_red[wave] = x;
                 __syncthreads();
-                if (tid == 0) st_sc1(&a.Tt[v], s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+                if (tid == 0) put_value(Ttg + 2 * v, tag, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
                 __syncthreads();
             }
-            drain_vm();
-            if (tid == 0) add_u32(cnt2, 1u);
         }
-        PROF(3);   // reduce role (incl. waiting for all arrivals)
-        tgt2 += (unsigned)(nv < W ? nv : W);
-        if (!wait_ge(cnt2, tgt2, abort_word, ctl)) { ok = false; break; }
-        PROF(4);   // wait for the totals
+        PROF(3);   // reduce role
+
+        // ---- loaders: fetch the column slices of upcoming positions (overlaps the exchange)
+        int want = pos + nb + SW_BMAX;
+        if (want > a.M) want = a.M;
+        int npf = want - hi;
+        if (npf > PFN) npf = PFN;
+        if (npf < 0) npf = 0;
+        if (loader) {
+#pragma unroll
+            for (int i = 0; i < PFN; i++) {
+                ld_t w = ODD;
+                if (i < npf && lvalid) w = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[hi + i] * a.stride + cb);
+                pf[i] = w;
+            }
+        }
 
         // ---- sampling step (wavefront 0, every workgroup, identical inputs) -------------
         if (wave == 0) {
+            const SampleOut so{a.acum, a.betas_out, a.comp};
+            bool okw = true;
             switch (K) {
-                case 2: sample_batch<2>(a, nb, smem, wg == 0); break;
-                case 3: sample_batch<3>(a, nb, smem, wg == 0); break;
-                case 4: sample_batch<4>(a, nb, smem, wg == 0); break;
-                case 5: sample_batch<5>(a, nb, smem, wg == 0); break;
-                case 6: sample_batch<6>(a, nb, smem, wg == 0); break;
-                case 7: sample_batch<7>(a, nb, smem, wg == 0); break;
-                default: sample_batch<8>(a, nb, smem, wg == 0); break;
+                case 2: okw = sample_batch<2>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
+                case 3: okw = sample_batch<3>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
+                case 4: okw = sample_batch<4>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
+                case 5: okw = sample_batch<5>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
+                case 6: okw = sample_batch<6>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
+                case 7: okw = sample_batch<7>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
+                default: okw = sample_batch<8>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
             }
+            bad |= !okw;
         }
-        __syncthreads();
-        PROF(5);   // sampling step
-        if (ctl[C_RNGERR]) { ok = false; break; }
+        if (__syncthreads_or(bad ? 1 : 0) || ctl[C_RNGERR]) { ok = false; break; }
+        PROF(5);   // wait for the totals + sampling step
 
-        // ---- phase C: residual update of the stopping marker ----------------------------
+        // ---- phase C: residual update of the stopping marker (its slice is in the ring) ----
         if (ctl[C_UPD]) {
             n_upd++;
-            if (valid) {
-                uint32_t wd[NW];
-                load_words<R>(a.bed + (size_t)ctl[C_MUPD] * a.stride + b0, wd);
+            const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((pos + ctl[C_SUPD]) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)tid * R);
 #pragma unroll
-                for (int w = 0; w < NW; w++) wd[w] = (wd[w] & keep[w]) | force[w];
-#pragma unroll
-                for (int i = 0; i < NI; i++) {
-                    const uint32_t c = (wd[i / IPW] >> (2 * (i % IPW))) & 3u;
-                    eps[i] += s_val[c];
-                    split2(eps[i], q1[i], q2[i]);
-                }
+            for (int i = 0; i < NI; i++) {
+                eps[i] += s_val[(wd >> (2 * i)) & 3u];
+                split2(eps[i], q1[i], q2[i]);
             }
         }
+        // ---- loaders: park the fetched slices in the ring (visible after the next barrier) --
+        if (loader) {
+#pragma unroll
+            for (int i = 0; i < PFN; i++)
+                if (i < npf) *reinterpret_cast<ld_t*>(ring + (size_t)((hi + i) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)lt * 2 * R) = (pf[i] & lkeep) | lforce;
+        }
+        hi += npf;
         pos += ctl[C_NDONE];
         gen++;
         n_batch++;
-        PROF(6);   // residual update
+        PROF(6);   // residual update + ring write
     }
 
     if (!ok) {
@@ -500,7 +578,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     }
     if (wg == 0) {
         for (int i = tid; i < 624; i += SW_TPB) a.rng_state[i] = s_rng0[i];
-        for (int i = tid; i < a.G * K; i += SW_TPB) a.cass[i] = s_cass[i];
+        for (int i = tid; i < G * K; i += SW_TPB) a.cass[i] = s_cass[i];
         if (tid == 0) {
             *a.rng_index = ctl[C_CURSOR];
             a.stats[0] = n_upd; a.stats[1] = n_batch; a.stats[2] = max_nb; a.stats[3] = 0;
@@ -512,8 +590,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #endif
 }
 
-// Bytes per thread: the smallest R in {1,2,4,8,16} whose grid fits max_wg workgroups.
+// Bytes per thread: the smallest R in {1,2,4} whose grid fits max_wg (<= 256) workgroups.
 int sweep_pick_R(size_t stride, int max_wg, int* W_out) {
+    if (max_wg > SW_TPB) max_wg = SW_TPB;            // one reducer thread per workgroup
     for (int R = 1; R <= 4; R *= 2) {
         const size_t per_wg = (size_t)SW_TPB * R;
         const size_t W = (stride + per_wg - 1) / per_wg;
@@ -522,29 +601,22 @@ int sweep_pick_R(size_t stride, int max_wg, int* W_out) {
     return -1;
 }
 
-hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st) {
-    const dim3 grid(a.W), block(SW_TPB);
-    hipError_t e = hipSuccess;
-    switch (R) {
-        case 1:
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<1>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_sweep<1>, grid, block, L_TOTAL, st, a);
-            break;
-        case 2:
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<2>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_sweep<2>, grid, block, L_TOTAL, st, a);
-            break;
-        case 4:
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<4>), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(k_sweep<4>, grid, block, L_TOTAL, st, a);
-            break;
-        default:
-            return hipErrorInvalidValue;
-    }
+template <int R> static hipError_t launch_R(const SweepArgs& a, hipStream_t st) {
+    const int lds = lds_total(R);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sweep<R>, dim3(a.W), dim3(SW_TPB), lds, st, a);
     return hipGetLastError();
+}
+
+hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st) {
+    if (a.W > SW_TPB) return hipErrorInvalidValue;
+    switch (R) {
+        case 1: return launch_R<1>(a, st);
+        case 2: return launch_R<2>(a, st);
+        case 4: return launch_R<4>(a, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace gm
