@@ -27,12 +27,15 @@ import torch.distributed as dist
 class HipEngine:
     """The product engine: gmrm_amd.Sampler + Context on this rank's GPU."""
 
-    def __init__(self, sampler, device):
+    def __init__(self, sampler, device, host_staging=False):
+        """host_staging=True routes the exchanged tensors through host memory (for the gloo
+        backend, e.g. two test ranks sharing one GPU); the default hands RCCL device memory."""
         self.s = sampler
         self.ctx = sampler.ctx
         self.T, self.G, self.K = self.ctx.T, sampler.G, sampler.K
         self.n4 = 4 * self.ctx.mbytes
         self.device = device
+        self.host_staging = host_staging
         self._q = torch.empty(2 * self.n4, dtype=torch.float64, device=device)
 
     def draw_mu(self, it):
@@ -47,9 +50,12 @@ class HipEngine:
     def delta_export(self, t):
         torch.cuda.current_stream(self.device).synchronize()
         self.ctx.eps_delta_export(t, self._q.data_ptr())
-        return self._q
+        return self._q.cpu() if self.host_staging else self._q
 
     def delta_import(self, t, q):
+        if self.host_staging:
+            self._q.copy_(q)
+            q = self._q
         torch.cuda.current_stream(self.device).synchronize()
         self.ctx.eps_delta_import(t, q.data_ptr())
 
@@ -64,7 +70,7 @@ class HipEngine:
         self.s.adopt(t, sigmag, pi, sigmae)
 
     def small(self, arr):
-        return torch.as_tensor(arr, device=self.device)
+        return torch.as_tensor(arr, device="cpu" if self.host_staging else self.device)
 
 
 class ShardedDriver:

@@ -1,0 +1,331 @@
+// gmrm_main.cpp -- command-line host program: gmrm's option surface and file formats on top
+// of the C ABI of libgmrm_hip.so (include/gmrm_hip.h).  Everything numerical happens behind
+// that ABI; this file is argument parsing, input decoding and output records.
+//
+// Mirrors, in the build's own code (file:line relative to /root/reference/):
+//   src/main.cpp:8-24            driver
+//   src/options.cpp:16-286       flags, validation, --group-mixture-file parser
+//   src/dimensions.cpp:8-29      --dim-file
+//   src/bayes.cpp:830-853        --group-index-file
+//   src/bayes.cpp:867-900        .bed block read (here: chunked pread -> gmrm_upload_bed)
+//   src/phenotype.cpp:587-621    --phen-files tokenising
+//   src/bayes.cpp:659-669, src/xfiles.hpp:14-38, src/xfiles.cpp:6-47   .csv/.bet/.cpn records
+// Not provided: --predict (post-processing, outside the hot path; DESIGN.md "Out of scope").
+#include "../../include/gmrm_hip.h"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Opts {
+    std::string bed_file, dim_file, bim_file, ref_bim_file, group_index_file, group_mixture_file, out_dir;
+    std::vector<std::string> phen_files;
+    int verbosity = 0;
+    bool shuffle = true, mimic_hydra = false, predict = false;
+    unsigned seed = 0, iterations = 1, truncm = 0, thin = 1;
+    int device = 0;
+};
+
+[[noreturn]] void fatal(const std::string& m) {
+    std::cout << m << std::endl;
+    std::exit(EXIT_FAILURE);
+}
+void need(int rc, const char* what) {
+    if (rc < 0) fatal(std::string("FATAL  : ") + what + ": " + gmrm_last_error());
+}
+double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+std::vector<std::string> split_ws(const std::string& line) {
+    std::vector<std::string> out;
+    std::istringstream ss(line);
+    std::string tok;
+    while (ss >> tok) out.push_back(tok);
+    return out;
+}
+std::string stem_of(const std::string& path) {               // fs::path::stem()
+    size_t slash = path.find_last_of('/');
+    std::string name = slash == std::string::npos ? path : path.substr(slash + 1);
+    size_t dot = name.find_last_of('.');
+    if (dot != std::string::npos && dot != 0) name = name.substr(0, dot);
+    return name;
+}
+
+// options.cpp:16-160: same flags, same messages
+Opts parse(int argc, char** argv) {
+    Opts o;
+    std::stringstream ss;
+    ss << "\nardyh command line options:\n";                  // options.cpp:22 (the program's former name)
+    auto last = [&](int i) {
+        if (i == argc - 1)
+            fatal(std::string("FATAL  : missing argument for last option \"") + argv[i] + "\". Please check your input and relaunch.");
+    };
+    auto positive = [&](int i, const char* name, int minv) {
+        if (atoi(argv[i + 1]) < minv)
+            fatal(std::string("FATAL  : option ") + name + " has to be a " + (minv == 0 ? "positive" : "strictly positive")
+                  + " integer! (" + argv[i + 1] + " was passed)");
+    };
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--bed-file") { last(i); o.bed_file = argv[++i]; ss << "--bed-file " << o.bed_file << "\n"; }
+        else if (a == "--dim-file") { last(i); o.dim_file = argv[++i]; ss << "--dim-file " << o.dim_file << "\n"; }
+        else if (a == "--phen-files") {
+            last(i);
+            std::string cslist = argv[++i];
+            ss << "--phen-files " << cslist << "\n";
+            std::stringstream sl(cslist);
+            std::string fp;
+            while (getline(sl, fp, ',')) {
+                std::ifstream f(fp);
+                if (!f.is_open()) fatal("FATAL: file " + fp + " not found");
+                o.phen_files.push_back(fp);
+            }
+        }
+        else if (a == "--group-index-file") { last(i); o.group_index_file = argv[++i]; ss << "--group-index-file " << o.group_index_file << "\n"; }
+        else if (a == "--group-mixture-file") { last(i); o.group_mixture_file = argv[++i]; ss << "--group-mixture-file " << o.group_mixture_file << "\n"; }
+        else if (a == "--verbosity") { last(i); o.verbosity = atoi(argv[++i]); ss << "--verbosity " << o.verbosity << "\n"; }
+        else if (a == "--shuffle-markers") { last(i); o.shuffle = (bool)atoi(argv[++i]); ss << "--shuffle-markers " << o.shuffle << "\n"; }
+        else if (a == "--mimic-hydra") { o.mimic_hydra = true; ss << "--mimic-hydra " << o.mimic_hydra << "\n"; }
+        else if (a == "--seed") { last(i); positive(i, "--seed", 0); o.seed = (unsigned)atoi(argv[++i]); ss << "--seed " << o.seed << "\n"; }
+        else if (a == "--iterations") { last(i); positive(i, "--iterations", 1); o.iterations = (unsigned)atoi(argv[++i]); ss << "--iterations " << o.iterations << "\n"; }
+        else if (a == "--trunc-markers") { last(i); positive(i, "--trunc-markers", 1); o.truncm = (unsigned)atoi(argv[++i]); ss << "--trunc-markers " << o.truncm << "\n"; }
+        else if (a == "--S") { last(i); ++i; ss << "--S " << argv[i] << "\n"; }           // parsed, never used upstream (options.cpp:105-119)
+        else if (a == "--out-dir") {
+            last(i);
+            o.out_dir = argv[++i];
+            struct stat st;
+            if (stat(o.out_dir.c_str(), &st) != 0) mkdir(o.out_dir.c_str(), 0777);       // single level, options.cpp:123-126
+            ss << "--out-dir " << o.out_dir << "\n";
+        }
+        else if (a == "--output-thin-rate") { last(i); positive(i, "--output-thin-rate", 1); o.thin = (unsigned)atoi(argv[++i]); ss << "--output-thin-rate " << o.thin << "\n"; }
+        else if (a == "--predict") { o.predict = true; ss << "--predict " << o.predict << "\n"; }
+        else if (a == "--bim-file") { last(i); o.bim_file = argv[++i]; ss << "--bim-file " << o.bim_file << "\n"; }
+        else if (a == "--ref-bim-file") { last(i); o.ref_bim_file = argv[++i]; ss << "--ref-bim-file " << o.ref_bim_file << "\n"; }
+        else if (a == "--device") { last(i); o.device = atoi(argv[++i]); ss << "--device " << o.device << "\n"; }   // this build only
+        else fatal("FATAL: option \"" + a + "\" unknown");
+    }
+    std::cout << ss.str() << std::endl;
+    // options.cpp:175-220
+    if (o.bed_file.empty()) fatal("FATAL  : no bed file provided! Please use the --bed-file option.");
+    if (o.dim_file.empty()) fatal("FATAL  : no dim file provided! Please use the --dim-file option.");
+    if (o.phen_files.empty()) fatal("FATAL  : no phen file(s) provided! Please use the --phen-files option.");
+    if (!o.predict && (o.group_index_file.empty() != o.group_mixture_file.empty()))
+        fatal("FATAL  : you need to activate BOTH --group-index-file and --group-mixture-file");
+    if (o.mimic_hydra && o.phen_files.size() > 1)
+        fatal("FATAL  : with --mimic-hydra, only a single phenotype can be processed.");
+    if (o.predict)
+        fatal("FATAL  : --predict (posterior-mean association statistics) is not part of this build: it covers the sampling hot path only.");
+    return o;
+}
+
+// options.cpp:222-286
+void read_mixtures(const std::string& path, std::vector<double>& cva, int& G, int& K) {
+    std::ifstream f(path);
+    if (!f.is_open()) { printf("FATAL  : can not open the mixture file %s. Use the --group-mixture-file option!\n", path.c_str()); std::exit(1); }
+    std::cout << "INFO   : Reading group mixtures from [" + path + "]." << std::endl;
+    std::string line;
+    G = 0; K = -1;
+    while (getline(f, line)) {
+        std::vector<std::string> tok = split_ws(line);
+        if (tok.empty()) continue;
+        if (K < 0) K = (int)tok.size();
+        if ((int)tok.size() != K) {
+            printf("FATAL  : check your mixture file. The same number of mixtures is expected for all groups.\n");
+            printf("       : got %d mixtures for group %d, while first group had %d.\n", (int)tok.size(), G, K);
+            std::exit(1);
+        }
+        for (int j = 0; j < K; j++) {
+            const double v = std::stod(tok[j]);
+            if (j == 0 && v != 0.0) { printf("FATAL  : First element of group mixture must be 0.0! Check your input file %s.\n", path.c_str()); std::exit(1); }
+            if (j > 0 && v <= cva.back()) { printf("FATAL  : Mixtures must be given in ascending order! Check your input file %s.\n", path.c_str()); std::exit(1); }
+            cva.push_back(v);
+        }
+        G++;
+    }
+}
+
+struct HistFile {                 // xfiles.hpp:14-38 via POSIX pwrite
+    int fd = -1;
+    void open_fresh(const std::string& p) {
+        unlink(p.c_str());                                        // bayes.cpp:323 delete_output_files
+        fd = open(p.c_str(), O_CREAT | O_WRONLY | O_EXCL, 0644);  // MPI_MODE_CREATE|WRONLY|EXCL
+        if (fd < 0) fatal("FATAL  : cannot create output file " + p);
+    }
+    void put(const void* buf, size_t n, off_t off) {
+        if (pwrite(fd, buf, n, off) != (ssize_t)n) fatal("FATAL  : short write on an output file");
+    }
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const Opts opt = parse(argc, argv);
+
+    // dimensions.cpp:8-29, dimensions.hpp:10-14
+    int N = 0, Mt = 0;
+    {
+        std::ifstream f(opt.dim_file);
+        if (!f.is_open()) fatal("FATAL: could not open dim file: " + opt.dim_file);
+        std::string line;
+        getline(f, line);
+        std::vector<std::string> tok = split_ws(line);
+        if (tok.size() != 2) fatal("FATAL: dim file should contain a single line with 2 integers");
+        N = atoi(tok[0].c_str());
+        Mt = atoi(tok[1].c_str());
+        if (opt.truncm > 0 && opt.truncm < (unsigned)Mt) Mt = (int)opt.truncm;
+    }
+    if (opt.group_mixture_file.empty())
+        fatal("FATAL  : can not open the mixture file . Use the --group-mixture-file option!");   // options.cpp:259-261
+    std::vector<double> cva;
+    int G = 0, K = 0;
+    read_mixtures(opt.group_mixture_file, cva, G, K);
+
+    if (gmrm_device_count() < 1) fatal("FATAL  : no HIP device visible; this build has no CPU path.");
+    const int T = (int)opt.phen_files.size();
+    printf("INFO   : rank %4d has %d markers over tot Mt = %d, max Mm = %d, starting at S = %d\n", 0, Mt, Mt, Mt, 0);
+    gmrm_ctx* ctx = nullptr;
+    need(gmrm_ctx_create(&ctx, opt.device, N, Mt, Mt, 0, T), "gmrm_ctx_create");
+
+    // bayes.cpp:867-900: marker-major block after 3 magic bytes (checked here; upstream skips them unchecked)
+    const size_t mbytes = ((size_t)N + 3) / 4;
+    {
+        const double ts = now();
+        int fd = open(opt.bed_file.c_str(), O_RDONLY);
+        if (fd < 0) fatal("FATAL  : cannot open bed file " + opt.bed_file);
+        unsigned char magic[3];
+        if (pread(fd, magic, 3, 0) != 3 || magic[0] != 0x6c || magic[1] != 0x1b || magic[2] != 0x01)
+            fatal("FATAL  : " + opt.bed_file + " is not a SNP-major PLINK .bed file (magic bytes 6c 1b 01 expected).");
+        const size_t chunk_markers = std::max<size_t>(1, (size_t)(256u << 20) / mbytes);
+        std::vector<unsigned char> buf(chunk_markers * mbytes);
+        printf("INFO   : rank %4d has allocated %zu bytes (%.3f GB) for raw data.\n", 0, (size_t)Mt * mbytes, double((size_t)Mt * mbytes) / 1.0E9);
+        for (size_t m0 = 0; m0 < (size_t)Mt; m0 += chunk_markers) {
+            const size_t nm = std::min(chunk_markers, (size_t)Mt - m0);
+            size_t got = 0;
+            while (got < nm * mbytes) {
+                ssize_t r = pread(fd, buf.data() + got, nm * mbytes - got, 3 + m0 * mbytes + got);
+                if (r <= 0) fatal("FATAL  : bed file shorter than the dim file says.");
+                got += (size_t)r;
+            }
+            need(gmrm_upload_bed(ctx, buf.data(), m0, nm), "gmrm_upload_bed");
+        }
+        close(fd);
+        printf("INFO   : time to load genotype data = %.2f seconds.\n", now() - ts);
+    }
+
+    // phenotype.cpp:587-673
+    std::vector<std::string> stems;
+    for (int t = 0; t < T; t++) {
+        std::ifstream f(opt.phen_files[t]);
+        if (!f.is_open()) fatal("FATAL: could not open phenotype file: " + opt.phen_files[t]);
+        std::vector<double> y;
+        std::vector<uint8_t> isna;
+        std::string line;
+        while (getline(f, line)) {
+            std::vector<std::string> tok = split_ws(line);
+            if (tok.size() < 3) continue;
+            if (tok[2] == "NA") { y.push_back(0.0); isna.push_back(1); }
+            else { y.push_back(atof(tok[2].c_str())); isna.push_back(0); }
+        }
+        if ((int)y.size() != N) {                                            // bayes.cpp:856-864
+            std::cout << "Fatal: N = " << N << " while phen file " << opt.phen_files[t] << " has " << y.size() << " individuals!" << std::endl;
+            std::exit(1);
+        }
+        std::vector<double> eps(4 * mbytes);
+        std::vector<uint8_t> mask4(mbytes);
+        int nonas = 0;
+        need(gmrm_phen_prepare(y.data(), isna.data(), N, eps.data(), mask4.data(), &nonas), "gmrm_phen_prepare");
+        if (N % 4 != 0) std::cout << "Setting last " << 4 - N % 4 << " bits to NAs" << std::endl;
+        need(gmrm_upload_trait(ctx, t, eps.data(), mask4.data(), nonas), "gmrm_upload_trait");
+        printf("INFO   : %s has %d NAs and %d non-NAs.\n", opt.phen_files[t].c_str(), N - nonas, nonas);
+        stems.push_back(stem_of(opt.phen_files[t]));
+    }
+    printf("INFO   : output directory: %s\n", opt.out_dir.c_str());
+
+    // bayes.cpp:830-853 (only column 2 is used; the upstream check is `group > G`, off by one)
+    std::vector<int> group_index;
+    {
+        std::ifstream f(opt.group_index_file);
+        if (!f) fatal("Error: can not open the group file [" + opt.group_index_file + "] to read. Use the --group-index-file option!");
+        std::cout << "INFO   : Reading groups from " + opt.group_index_file + "." << std::endl;
+        std::string label;
+        int group;
+        while (f >> label >> group) {
+            if (group >= G || group < 0) {
+                printf("FATAL  : group index file contains a value that exceeds the number of groups given in group mixture file.\n");
+                printf("       : check the consistency between your group index and mixture input files.\n");
+                std::exit(1);
+            }
+            group_index.push_back(group);
+        }
+        if ((int)group_index.size() < Mt) fatal("FATAL  : group index file has fewer lines than markers.");
+        group_index.resize(Mt);
+    }
+
+    gmrm_sampler_opts so{};
+    so.seed = opt.seed; so.rank = 0; so.nranks = 1; so.shuffle = opt.shuffle; so.mimic_hydra = opt.mimic_hydra;
+    so.G = G; so.K = K; so.cva = cva.data(); so.group_index = group_index.data();
+    gmrm_sampler* smp = nullptr;
+    {
+        const double ts = now();
+        need(gmrm_sampler_create(&smp, ctx, &so), "gmrm_sampler_create");   // computes the markers' statistics
+        printf("INFO   : Time to compute the markers' statistics: %.2f seconds.\n", now() - ts);
+    }
+    need(gmrm_sampler_init(smp), "gmrm_sampler_init");
+
+    // phenotype.cpp:129-143: <out_dir>/<phen stem>.{bet,cpn,csv}
+    std::vector<HistFile> fbet(T), fcpn(T), fcsv(T);
+    for (int t = 0; t < T; t++) {
+        std::string base = opt.out_dir.empty() ? stems[t] : opt.out_dir + "/" + stems[t];
+        fbet[t].open_fresh(base + ".bet");
+        fcpn[t].open_fresh(base + ".cpn");
+        fcsv[t].open_fresh(base + ".csv");
+    }
+    std::vector<double> betas(Mt);
+    std::vector<int> comp(Mt);
+    std::vector<char> line(50000);                                          // const.hpp:3 LENBUF
+    const unsigned Mtot = (unsigned)Mt;
+    for (unsigned it = 1; it <= opt.iterations; it++) {
+        const double ts = now();
+        printf("\n\n@@@ ITERATION %5d\n", it);
+        need(gmrm_sampler_iterate(smp, (int)it), "gmrm_sampler_iterate");
+        for (int t = 0; t < T; t++) {
+            gmrm_hyper h;
+            need(gmrm_sampler_get(smp, t, &h), "gmrm_sampler_get");
+            double sg = 0.0;
+            for (int g = 0; g < G; g++) sg += h.sigmag[g];
+            printf("RESULT : i:%d r:%d p:%d  sum sigmaG = %20.15f  sigmaE = %20.15f\n", it, 0, t, sg, h.sigmae);
+        }
+        printf("RESULT : It %d  total proc time = %7.3f sec, with sync time = %7.3f\n", it, now() - ts, 0.0);
+        if (it % opt.thin == 0) {                                           // bayes.cpp:659-669
+            const unsigned nth = it / opt.thin - 1;
+            for (int t = 0; t < T; t++) {
+                const int n = gmrm_sampler_csv_line(smp, t, (int)it, line.data(), line.size());
+                need(n, "gmrm_sampler_csv_line");
+                fcsv[t].put(line.data(), (size_t)n, (off_t)nth * n);        // xfiles.cpp:45
+                need(gmrm_get_betas(ctx, t, betas.data()), "gmrm_get_betas");
+                need(gmrm_get_comp(ctx, t, comp.data()), "gmrm_get_comp");
+                if (nth == 0) { fbet[t].put(&Mtot, 4, 0); fcpn[t].put(&Mtot, 4, 0); }
+                const off_t ob = 4 + (off_t)nth * (4 + (off_t)Mtot * 8), oc = 4 + (off_t)nth * (4 + (off_t)Mtot * 4);
+                fbet[t].put(&it, 4, ob); fbet[t].put(betas.data(), (size_t)Mtot * 8, ob + 4);
+                fcpn[t].put(&it, 4, oc); fcpn[t].put(comp.data(), (size_t)Mtot * 4, oc + 4);
+            }
+        }
+        fflush(stdout);
+    }
+    for (int t = 0; t < T; t++) { close(fbet[t].fd); close(fcpn[t].fd); close(fcsv[t].fd); }
+    gmrm_sampler_destroy(smp);
+    gmrm_ctx_destroy(ctx);
+    return 0;
+}

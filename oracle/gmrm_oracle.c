@@ -788,6 +788,7 @@ double* orc_chain_mave(orc_chain* c) { return c->mave; }
 double* orc_chain_msig(orc_chain* c) { return c->msig; }
 double  orc_chain_sigmae(orc_chain* c) { return c->sigmae; }
 double  orc_chain_mu(orc_chain* c) { return c->mu; }
+void    orc_chain_set_sigmae(orc_chain* c, double v) { c->sigmae = v; }
 long    orc_chain_nupdates(orc_chain* c) { return c->n_updates; }
 orc_rng* orc_chain_rng_d(orc_chain* c) { return &c->dist_d; }
 orc_rng* orc_chain_rng_m(orc_chain* c) { return &c->dist_m; }

@@ -117,6 +117,7 @@ double* orc_chain_mave(orc_chain* c);
 double* orc_chain_msig(orc_chain* c);
 double  orc_chain_sigmae(orc_chain* c);
 double  orc_chain_mu(orc_chain* c);
+void    orc_chain_set_sigmae(orc_chain* c, double v);
 int     orc_chain_m0_sum(orc_chain* c);
 long    orc_chain_nupdates(orc_chain* c);
 orc_rng* orc_chain_rng_d(orc_chain* c);

@@ -98,6 +98,7 @@ _SIGS = {
     "orc_chain_msig": (c_double_p, [C.c_void_p]),
     "orc_chain_sigmae": (C.c_double, [C.c_void_p]),
     "orc_chain_mu": (C.c_double, [C.c_void_p]),
+    "orc_chain_set_sigmae": (None, [C.c_void_p, C.c_double]),
     "orc_chain_m0_sum": (C.c_int, [C.c_void_p]),
     "orc_chain_nupdates": (C.c_long, [C.c_void_p]),
     "orc_chain_rng_d": (C.POINTER(OrcRng), [C.c_void_p]),

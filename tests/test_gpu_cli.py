@@ -1,0 +1,69 @@
+"""GPU test of the command-line host (bin/gmrm_hip): gmrm's flags in, gmrm's .bet/.cpn/.csv
+out, byte-compared with records built from the oracle chain."""
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from gmrm_amd import io
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+BIN = ROOT / "bin" / "gmrm_hip"
+
+
+def _write_inputs(d, case, inp):
+    io.write_bed(d / "t.bed", inp["bed"])
+    (d / "t.dim").write_text(f"{case.N} {case.M}\n")
+    (d / "t.gri").write_text("".join(f"{i} {g}\n" for i, g in enumerate(inp["group_index"])))
+    (d / "t.grm").write_text("".join(" ".join(f"{v:.5f}" for v in row) + "\n" for row in inp["cva"]))
+    phens = []
+    for t in range(inp["y"].shape[0]):
+        p = d / f"trait{t}.phen"
+        with open(p, "w") as f:
+            for i in range(case.N):
+                v = "NA" if inp["isna"][t][i] else repr(float(inp["y"][t][i]))
+                f.write(f"{i + 1} {i + 1} {v}\n")
+        phens.append(p)
+    return phens
+
+
+@pytest.mark.parametrize("name,thin", [("small", 1), ("ragged", 2)])
+def test_cli_outputs_match_oracle(gpu, tmp_path, name, thin):
+    assert BIN.exists(), "bin/gmrm_hip not built (python __graft_entry__.py)"
+    case = cases.CASE_BY_NAME[name]
+    inp = cases.make_inputs(case)
+    # the .grm text carries 5 decimals: make the oracle use exactly what the file says
+    inp["cva"] = np.array([[float(f"{v:.5f}") for v in row] for row in inp["cva"]])
+    phens = _write_inputs(tmp_path, case, inp)
+    out = tmp_path / "out"
+    iters = 4
+    cmd = [str(BIN), "--bed-file", str(tmp_path / "t.bed"), "--dim-file", str(tmp_path / "t.dim"),
+           "--phen-files", ",".join(str(p) for p in phens), "--group-index-file", str(tmp_path / "t.gri"),
+           "--group-mixture-file", str(tmp_path / "t.grm"), "--shuffle-markers", "1", "--seed", str(case.seed),
+           "--iterations", str(iters), "--out-dir", str(out), "--output-thin-rate", str(thin)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ardyh command line options" in r.stdout and "RESULT : It 4" in r.stdout
+    want = cases.run_oracle(case, inp, iters=iters, canon=True)
+    saved = [it for it in range(1, iters + 1) if it % thin == 0]
+    for t, h in enumerate(want):
+        stem = out / f"trait{t}"
+        bet = b"".join([struct.pack("<I", case.M)] + [struct.pack("<I", it) + h["betas"][it - 1].tobytes() for it in saved])
+        cpn = b"".join([struct.pack("<I", case.M)] + [struct.pack("<I", it) + h["comp"][it - 1].astype("<i4").tobytes() for it in saved])
+        csv = b"".join(h["csv"][it - 1] for it in saved)
+        assert Path(str(stem) + ".bet").read_bytes() == bet
+        assert Path(str(stem) + ".cpn").read_bytes() == cpn
+        assert Path(str(stem) + ".csv").read_bytes() == csv
+
+
+def test_cli_option_errors(gpu, tmp_path):
+    r = subprocess.run([str(BIN)], capture_output=True, text=True)
+    assert r.returncode == 1 and "no bed file provided" in r.stdout
+    r = subprocess.run([str(BIN), "--frobnicate"], capture_output=True, text=True)
+    assert r.returncode == 1 and 'option "--frobnicate" unknown' in r.stdout
+    r = subprocess.run([str(BIN), "--iterations", "0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "strictly positive" in r.stdout
