@@ -92,6 +92,7 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
         HIPCHK(dalloc(&tr.namask2, c->stride));
         HIPCHK(dalloc(&tr.mave, Mm));
         HIPCHK(dalloc(&tr.msig, Mm));
+        HIPCHK(dalloc(&tr.nomiss, Mm));
         HIPCHK(dalloc(&tr.betas[0], Mm));
         HIPCHK(dalloc(&tr.betas[1], Mm));
         HIPCHK(dalloc(&tr.comp, Mm));
@@ -101,7 +102,7 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
         HIPCHK(dalloc(&tr.rng_state, (size_t)624));
         HIPCHK(dalloc(&tr.rng_index, (size_t)4));
         HIPCHK(dalloc(&tr.cass, (size_t)GMAX * KMAX));
-        HIPCHK(dalloc(&tr.stats, (size_t)20));
+        HIPCHK(dalloc(&tr.stats, (size_t)24));
         HIPCHK(dalloc(&tr.err, (size_t)4));
         HIPCHK(dalloc(&tr.P, (size_t)2 * SW_VMAX * c->Wpad));       // two 8-byte granules per value
         HIPCHK(dalloc(&tr.Tt, (size_t)2 * SW_VMAX));
@@ -120,7 +121,7 @@ int gmrm_ctx_destroy(gmrm_ctx* c) {
     hipSetDevice(c->device);
     for (auto& tr : c->tr) {
         if (tr.stream) hipStreamSynchronize(tr.stream);
-        hipFree(tr.eps); hipFree(tr.eps_start); hipFree(tr.namask2); hipFree(tr.mave); hipFree(tr.msig);
+        hipFree(tr.eps); hipFree(tr.eps_start); hipFree(tr.namask2); hipFree(tr.mave); hipFree(tr.msig); hipFree(tr.nomiss);
         hipFree(tr.betas[0]); hipFree(tr.betas[1]); hipFree(tr.comp); hipFree(tr.acum); hipFree(tr.order);
         hipFree(tr.tab); hipFree(tr.rng_state); hipFree(tr.rng_index); hipFree(tr.cass); hipFree(tr.stats);
         hipFree(tr.err); hipFree(tr.P); hipFree(tr.Tt); hipFree(tr.cnt); hipFree(tr.scratch);
@@ -250,7 +251,7 @@ int gmrm_marker_stats(gmrm_ctx* c, int t) {
     if (int r = need_trait(c, t, true)) return r;
     HIPCHK(hipSetDevice(c->device));
     Trait& tr = c->tr[t];
-    HIPCHK(launch_marker_stats(c->bed, tr.namask2, c->stride, c->M, tr.nonas, tr.mave, tr.msig, tr.stream));
+    HIPCHK(launch_marker_stats(c->bed, tr.namask2, c->stride, c->M, tr.nonas, tr.mave, tr.msig, tr.nomiss, tr.stream));
     HIPCHK(hipStreamSynchronize(tr.stream));
     tr.have_stats = true;
     return GMRM_OK;
@@ -271,6 +272,7 @@ int gmrm_set_marker_stats(gmrm_ctx* c, int t, const double* mave, const double* 
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(c->tr[t].mave, mave, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->tr[t].msig, msig, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(c->tr[t].nomiss, 0, (size_t)(c->M > 0 ? c->M : 1)));   // unknown: general exchange layout
     c->tr[t].have_stats = true;
     return GMRM_OK;
 }
@@ -402,13 +404,13 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     HIPCHK(hipMemsetAsync(tr.P, 0, (size_t)2 * SW_VMAX * c->Wpad * sizeof(double), tr.stream));
     HIPCHK(hipMemsetAsync(tr.Tt, 0, (size_t)2 * SW_VMAX * sizeof(double), tr.stream));
     HIPCHK(hipMemsetAsync(tr.err, 0, 4 * sizeof(int), tr.stream));
-    HIPCHK(hipMemsetAsync(tr.stats, 0, 20 * sizeof(long long), tr.stream));
+    HIPCHK(hipMemsetAsync(tr.stats, 0, 24 * sizeof(long long), tr.stream));
 
     SweepArgs a{};
     a.N = c->N; a.M = c->M; a.W = c->W; a.Wpad = c->Wpad; a.G = G; a.K = K;
     a.stride = c->stride;
     a.bed = c->bed; a.namask2 = tr.namask2; a.order = tr.order; a.group = c->group;
-    a.mave = tr.mave; a.msig = tr.msig;
+    a.mave = tr.mave; a.msig = tr.msig; a.nomiss = tr.nomiss;
     a.betas_in = tr.betas[tr.cur]; a.betas_out = tr.betas[tr.cur ^ 1];
     a.comp = tr.comp; a.acum = tr.acum; a.eps = tr.eps;
     a.sigmag = tr.tab; a.denom = tr.tab + G; a.logpi = tr.tab + G + (size_t)G * K; a.mhl = tr.tab + G + 2 * (size_t)G * K;
@@ -448,17 +450,20 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
     if (err[0] == 2) return fail(GMRM_EKERNEL, "sweep kernel: RNG window exhausted inside one batch");
     tr.cur ^= 1;
     if (out) {
-        long long st[20];
+        long long st[24];
         HIPCHK(hipMemcpy(st, tr.stats, sizeof(st), hipMemcpyDeviceToHost));
         out->n_updates = st[0]; out->n_batches = st[1];
         if (std::getenv("GMRM_SWEEP_PROF")) {                  // diagnostic build only (-DGM_SWEEP_PROF)
-            static const char* nm[7] = {"prologue", "dots", "publish", "reduce", "wait_totals", "sample", "update"};
+            static const char* nm[8] = {"prologue", "dots", "publish", "reduce", "wait_totals", "post_barrier", "update", "sample"};
             for (int w = 0; w < 2; w++) {
                 std::fprintf(stderr, "[sweep prof wg %s] batches %lld:", w ? "W/2" : "0", st[1]);
-                for (int i = 0; i < 7; i++)
+                for (int i = 0; i < 8; i++)
                     std::fprintf(stderr, " %s %.2fus", nm[i], st[1] ? st[(w ? 12 : 4) + i] * 0.01 / (double)st[1] : 0.0);
                 std::fprintf(stderr, "\n");
             }
+            std::fprintf(stderr, "[sweep prof sampler wg W/2] inputs %.2fus decide0 %.2fus search %.2fus commit %.2fus\n",
+                         st[20] * 0.01 / (double)st[1], st[21] * 0.01 / (double)st[1], st[22] * 0.01 / (double)st[1],
+                         st[23] * 0.01 / (double)st[1]);
         }
         if (out->cass) HIPCHK(hipMemcpy(out->cass, tr.cass, sizeof(int) * (size_t)tr.G * tr.K, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out->rng_state, tr.rng_state, 624 * sizeof(uint32_t), hipMemcpyDeviceToHost));

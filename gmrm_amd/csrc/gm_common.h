@@ -64,12 +64,21 @@ GM_HD double fma_(double a, double b, double c) {
 // ziggurat wedge tests.  Argument reduction by ln2 (hi/lo), degree-13 Taylor/Horner in
 // fma, scaling by two exact powers of two.  ~1 ulp.
 GM_HD double exp_(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // same values as the branching form below, written with selects (no divergent branches)
+    const bool is_nan = x != x;
+    const bool over = x > 0x1.62e42fefa39efp+9;
+    const bool under = x < -0x1.74910d52d3052p+9;
+    const double xc = (is_nan || over || under) ? 0.0 : x;
+#else
     if (x != x) return x;
     if (x > 0x1.62e42fefa39efp+9) return __builtin_huge_val();
     if (x < -0x1.74910d52d3052p+9) return 0.0;
-    const double t = x * 0x1.71547652b82fep+0;
+    const double xc = x;
+#endif
+    const double t = xc * 0x1.71547652b82fep+0;
     const double kd = (t + 0x1.8p52) - 0x1.8p52;
-    double r = fma_(-kd, 0x1.62e42fee00000p-1, x);
+    double r = fma_(-kd, 0x1.62e42fee00000p-1, xc);
     r = fma_(-kd, 0x1.a39ef35793c76p-33, r);
     double p = 0x1.6124613a86d09p-33;
     p = fma_(p, r, 0x1.1eed8eff8d898p-29);
@@ -89,7 +98,12 @@ GM_HD double exp_(double x) {
     const int k1 = k / 2, k2 = k - k1;
     const double s1 = __builtin_bit_cast(double, (uint64_t)(k1 + 1023) << 52);
     const double s2 = __builtin_bit_cast(double, (uint64_t)(k2 + 1023) << 52);
-    return (p * s1) * s2;
+    const double v = (p * s1) * s2;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return is_nan ? x : (over ? __builtin_huge_val() : (under ? 0.0 : v));
+#else
+    return v;
+#endif
 }
 
 GM_HD uint32_t mt_temper(uint32_t y) {

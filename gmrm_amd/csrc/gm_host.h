@@ -16,6 +16,7 @@ struct Trait {
     uint8_t* namask2 = nullptr;     // Phenotype::mask4 expanded to 2 bits per individual [stride]
     double* mave = nullptr;         // Phenotype::mave [M]
     double* msig = nullptr;         // Phenotype::msig [M]
+    uint8_t* nomiss = nullptr;      // [M] marker has no missing genotype among phenotyped individuals
     double* betas[2] = {nullptr, nullptr};   // Phenotype::betas [M], double-buffered per sweep
     int cur = 0;
     int* comp = nullptr;            // Phenotype::comp [M]

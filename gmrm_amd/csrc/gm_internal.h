@@ -25,6 +25,7 @@ struct SweepArgs {
     const int* group;              // [M] group of each local marker
     const double* mave;            // [M]
     const double* msig;            // [M]
+    const uint8_t* nomiss;         // [M] 1 = no missing genotype among the phenotyped individuals
     const double* betas_in;        // [M] effects before this sweep
     double* betas_out;             // [M] effects after this sweep
     int* comp;                     // [M]
@@ -60,7 +61,7 @@ hipError_t launch_offset(double* eps, const uint8_t* namask2, size_t stride, dou
 hipError_t launch_sumsq(const double* eps, const uint8_t* namask2 /*or null*/, size_t n, double* out2 /*zeroed*/,
                         double* outmax, hipStream_t st);
 hipError_t launch_marker_stats(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, int nonas,
-                               double* mave, double* msig, hipStream_t st);
+                               double* mave, double* msig, uint8_t* nomiss, hipStream_t st);
 hipError_t launch_synth(uint8_t* bed, size_t stride, int N, int M, int S, uint64_t seed,
                         double maf, double miss, hipStream_t st);
 hipError_t launch_delta_export(const double* eps, const double* start, double* q, size_t n4, hipStream_t st);

@@ -167,7 +167,8 @@ hipError_t launch_sumsq(const double* eps, const uint8_t* namask2, size_t n, dou
 // with n_c = #{present individuals with code c}, v0 = 2-mave, v2 = 1-mave, v3 = 0-mave.
 __global__ __launch_bounds__(256) void k_marker_stats(const uint8_t* __restrict__ bed,
                                                       const uint8_t* __restrict__ namask2, size_t stride, int M,
-                                                      int nonas, double* __restrict__ mave, double* __restrict__ msig) {
+                                                      int nonas, double* __restrict__ mave, double* __restrict__ msig,
+                                                      uint8_t* __restrict__ nomiss) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + wave;
     if (m >= M) return;
@@ -201,13 +202,14 @@ __global__ __launch_bounds__(256) void k_marker_stats(const uint8_t* __restrict_
         s += (double)n3 * (v3 * v3);
         mave[m] = av;
         msig[m] = 1.0 / __builtin_sqrt(s / ((double)nonas - 1.0));
+        nomiss[m] = (n0 + n2 + n3 == nonas) ? 1 : 0;      // no code 01 among the phenotyped individuals
     }
 }
 
 hipError_t launch_marker_stats(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, int nonas,
-                               double* mave, double* msig, hipStream_t st) {
+                               double* mave, double* msig, uint8_t* nomiss, hipStream_t st) {
     if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_marker_stats, dim3((M + 3) / 4), dim3(256), 0, st, bed, namask2, stride, M, nonas, mave, msig);
+    hipLaunchKernelGGL(k_marker_stats, dim3((M + 3) / 4), dim3(256), 0, st, bed, namask2, stride, M, nonas, mave, msig, nomiss);
     return hipGetLastError();
 }
 

@@ -45,7 +45,7 @@ constexpr int PFN      = 24;                    // positions prefetched per batc
 constexpr int L_LUT  = 0;                       // double2[4]   (a,b) per 2-bit code
 constexpr int L_VAL  = 64;                      // double[4]    update table of the stopping marker
 constexpr int L_CTL  = 96;                      // int[16]      control words
-constexpr int L_M    = 160;                     // int[64]      (spare)
+constexpr int L_M    = 160;                     // double[4]    a per 2-bit code (+ spare)
 constexpr int L_RNG0 = 416;                     // uint32[624]  current MT block (untempered)
 constexpr int L_RNG1 = L_RNG0 + 2496;           // uint32[624]  next MT block
 constexpr int L_CASS = L_RNG1 + 2496;           // int[GMAX*KMAX]
@@ -59,7 +59,7 @@ constexpr int L_MIN = 84 * 1024;
 constexpr int lds_total(int R) { return (L_RING + RING_POS * SW_TPB * R) > L_MIN ? (L_RING + RING_POS * SW_TPB * R) : L_MIN; }
 static_assert(lds_total(4) <= 160 * 1024, "LDS budget");
 
-enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR };
+enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_FAST, C_BAD };
 
 size_t sweep_lds_bytes() { return (size_t)lds_total(4); }
 
@@ -84,6 +84,81 @@ __device__ __forceinline__ bool get_value(const unsigned long long* g, unsigned 
     v = __longlong_as_double((long long)((g0 & 0xffffffffull) | (g1 << 32)));
     return (unsigned)(g0 >> 32) == tag && (unsigned)(g1 >> 32) == tag;
 }
+
+// ---- cross-lane helpers for the wavefront reductions (gfx950: v_permlane{16,32}_swap, DPP) ----
+__device__ __forceinline__ unsigned lo32(double x) { return (unsigned)(unsigned long long)__double_as_longlong(x); }
+__device__ __forceinline__ unsigned hi32(double x) { return (unsigned)((unsigned long long)__double_as_longlong(x) >> 32); }
+__device__ __forceinline__ double mk64(unsigned lo, unsigned hi) {
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// a' = [a.lanes0-31, b.lanes0-31], b' = [a.lanes32-63, b.lanes32-63]
+__device__ __forceinline__ void swap32(double& a, double& b) {
+    const auto l = __builtin_amdgcn_permlane32_swap(lo32(a), lo32(b), false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(hi32(a), hi32(b), false, false);
+    a = mk64(l[0], h[0]); b = mk64(l[1], h[1]);
+}
+// rows of 16 lanes: a' = [a.r0, b.r0, a.r2, b.r2], b' = [a.r1, b.r1, a.r3, b.r3]
+__device__ __forceinline__ void swap16(double& a, double& b) {
+    const auto l = __builtin_amdgcn_permlane16_swap(lo32(a), lo32(b), false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(hi32(a), hi32(b), false, false);
+    a = mk64(l[0], h[0]); b = mk64(l[1], h[1]);
+}
+template <int CTRL> __device__ __forceinline__ double dpp64(double x) {
+    const int l = __builtin_amdgcn_update_dpp(0, (int)lo32(x), CTRL, 0xf, 0xf, false);
+    const int h = __builtin_amdgcn_update_dpp(0, (int)hi32(x), CTRL, 0xf, 0xf, false);
+    return mk64((unsigned)l, (unsigned)h);
+}
+constexpr int DPP_ROW_MIRROR = 0x140;        // lane ^ 15 within a row of 16
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;   // lane ^ 7
+constexpr int DPP_QUAD_3210 = 0x1B;          // lane ^ 3
+constexpr int DPP_QUAD_1032 = 0xB1;          // lane ^ 1
+
+// 32 per-lane values -> lane l holds value (l >> 1) summed over the 64 lanes.  Each step pairs
+// lanes that agree on every earlier selector bit (masks 32, 16, 15, 7, 3, then 1), so the sums
+// telescope exactly like an xor butterfly; the sums are exact, so the pairing order is free.
+__device__ __forceinline__ double reduce32(double (&acc)[32], int lane) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) { swap32(acc[i], acc[i + 16]); acc[i] = acc[i] + acc[i + 16]; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { swap16(acc[i], acc[i + 8]); acc[i] = acc[i] + acc[i + 8]; }
+    {
+        const bool up = (lane & 8) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double send = up ? acc[i] : acc[i + 4], keep = up ? acc[i + 4] : acc[i];
+            acc[i] = keep + dpp64<DPP_ROW_MIRROR>(send);
+        }
+    }
+    {
+        const bool up = (lane & 4) != 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const double send = up ? acc[i] : acc[i + 2], keep = up ? acc[i + 2] : acc[i];
+            acc[i] = keep + dpp64<DPP_ROW_HALF_MIRROR>(send);
+        }
+    }
+    {
+        const bool up = (lane & 2) != 0;
+        const double send = up ? acc[0] : acc[1], keep = up ? acc[1] : acc[0];
+        acc[0] = keep + dpp64<DPP_QUAD_3210>(send);
+    }
+    return acc[0] + dpp64<DPP_QUAD_1032>(acc[0]);
+}
+// two per-lane values -> lanes 0-31 hold sum(a), lanes 32-63 hold sum(b)
+__device__ __forceinline__ double reduce2(double a, double b) {
+    swap32(a, b);
+    double x = a + b;
+    x += __shfl_xor(x, 16, 64);
+    x += dpp64<DPP_ROW_MIRROR>(x);
+    x += dpp64<DPP_ROW_HALF_MIRROR>(x);
+    x += dpp64<DPP_QUAD_3210>(x);
+    x += dpp64<DPP_QUAD_1032>(x);
+    return x;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, which
+// would make the loader wavefronts wait here for their in-flight genotype prefetches.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Spin budget shared by every poll loop: give up after ~4 s of wall clock or when another
 // workgroup has raised the abort word.
@@ -137,13 +212,11 @@ __device__ void block_advance(uint32_t* s0, uint32_t* s1, int* ctl, bool copy) {
     __syncthreads();
 }
 
-// bayes.cpp:403-477 for one marker, given num (the dot product + beta*(nonas-1)) and the
-// uniform draw: returns the chosen component, the acum value and muk/denom of that component.
+// bayes.cpp:403-445 for one marker, given num (the dot product + beta*(nonas-1)): muk, logl and
+// the probability of component 0 (the first value of "acum").  Evaluated by every lane.
 template <int K>
-__device__ __forceinline__ void decide(double num, double prob, const double* denom_g, const double* logpi_g,
-                                       const double* mhl_g, double inv2sige, int& kc, double& acum_v,
-                                       double& muk_c, double& denom_c) {
-    double muk[K], logl[K];
+__device__ __forceinline__ double decide0(double num, const double* denom_g, const double* logpi_g,
+                                          const double* mhl_g, double inv2sige, double (&muk)[K], double (&logl)[K]) {
     muk[0] = 0.0;
     logl[0] = logpi_g[0];
 #pragma unroll
@@ -157,9 +230,15 @@ __device__ __forceinline__ void decide(double num, double prob, const double* de
     for (int i = 0; i < K; i++) {
         const double d = logl[i] - logl[0];
         if (fabs(d) > 700.0) zero_acum = true;
-        tmp1 += exp_(d);
+        tmp1 += (d == 0.0) ? 1.0 : exp_(d);          // exp_(0) is exactly 1
     }
-    double acum = zero_acum ? 0.0 : 1.0 / tmp1;
+    return zero_acum ? 0.0 : 1.0 / tmp1;
+}
+// bayes.cpp:450-477: the component search.  Only the lane that stops the walk needs it (a lane
+// whose draw exceeds acum0 ends with a component > 0, i.e. it is the stopping lane).
+template <int K>
+__device__ __forceinline__ void decide_rest(double prob, double acum0, const double (&logl)[K], int& kc, double& acum_v) {
+    double acum = acum0;
     kc = K - 1;
     bool done = false;
 #pragma unroll
@@ -176,18 +255,16 @@ __device__ __forceinline__ void decide(double num, double prob, const double* de
                 if (!zero_inc) {
                     double esum = 0.0;
 #pragma unroll
-                    for (int k = 0; k < K; k++) esum += exp_(logl[k] - logl[i + 1 < K ? i + 1 : K - 1]);
+                    for (int k = 0; k < K; k++) {
+                        const double d = logl[k] - logl[i + 1 < K ? i + 1 : K - 1];
+                        esum += (d == 0.0) ? 1.0 : exp_(d);
+                    }
                     acum = acum + 1.0 / esum;
                 }
             }
         }
     }
     acum_v = acum;
-    muk_c = 0.0;
-    denom_c = 1.0;
-#pragma unroll
-    for (int i = 1; i < K; i++)
-        if (i == kc) { muk_c = muk[i]; denom_c = denom_g[i]; }
 }
 
 // What lane j of the sampling wavefront needs about batch position j; fetched at batch
@@ -196,6 +273,10 @@ struct LaneIn {
     int m, g;
     double beta_old, mave, msig;
 };
+// Exchange layouts.  General: 4 values per marker (sum a*q1, a*q2, b*q1, b*q2).  Fast (no marker
+// of the batch has a missing genotype among the phenotyped individuals, so b == 1 wherever the
+// residual is non-zero): 2 values per marker (sum a*q1, a*q2) + 2 per batch (sum q1, sum q2 over
+// all individuals = the b-sums of every such marker).
 struct SampleOut {                 // global outputs, written by workgroup 0 only
     double* acum;
     double* betas_out;
@@ -205,10 +286,17 @@ struct SampleOut {                 // global outputs, written by workgroup 0 onl
 // The Gibbs step for a whole batch, run by wavefront 0 of EVERY workgroup on identical
 // inputs.  Lane j handles batch position j; the walk stops at the first lane whose effect
 // may change.  Returns false on a poll timeout.
+#ifdef GM_SWEEP_PROF
+#define SSTAMP(i) do { if (lane == 0) { unsigned long long* sp_ = reinterpret_cast<unsigned long long*>(smem + L_M + 64); \
+                       const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); sp_[i] += t_ - sp_[7]; sp_[7] = t_; } } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
+
 template <int K>
-__device__ __noinline__ bool sample_batch(int nb, int G, char* smem, const LaneIn in, const unsigned long long* Ttg,
-                                          unsigned tag, double sigmae, double inv2sige, double nm1,
-                                          const SampleOut out, bool writer, unsigned* abort_word) {
+__device__ __noinline__ void sample_batch(int nb, int G, char* smem, const LaneIn in, double t0, double t1,
+                                          double t2, double t3, double sigmae, double inv2sige, double nm1,
+                                          const SampleOut out, bool writer) {
     const int lane = threadIdx.x & 63;
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     double* s_val = reinterpret_cast<double*>(smem + L_VAL);
@@ -217,6 +305,9 @@ __device__ __noinline__ bool sample_batch(int nb, int G, char* smem, const LaneI
     LdsStream rs{reinterpret_cast<const uint32_t*>(smem + L_RNG0), reinterpret_cast<const uint32_t*>(smem + L_RNG1),
                  ctl[C_CURSOR], &ctl[C_RNGERR]};
 
+#ifdef GM_SWEEP_PROF
+    if (lane == 0) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[7] = __builtin_amdgcn_s_memrealtime();
+#endif
     const bool act = lane < nb;
     const int m = in.m, g = in.g;
     const double beta_old = in.beta_old;
@@ -227,40 +318,33 @@ __device__ __noinline__ bool sample_batch(int nb, int G, char* smem, const LaneI
     const int cursor0 = rs.cursor;
     const double prob = unif_from_word(rs.peek(cursor0 + prefix));   // bayes.cpp:435
 
-    // the four totals of this lane's marker (tagged granules, polled until they arrive)
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    {
-        Spin sp;
-        sp.start();
-        bool bad = false;
-        for (;;) {
-            bool ok = true;
-            if (use) {
-                ok &= get_value(Ttg + 2 * (4 * lane + 0), tag, t0);
-                ok &= get_value(Ttg + 2 * (4 * lane + 1), tag, t1);
-                ok &= get_value(Ttg + 2 * (4 * lane + 2), tag, t2);
-                ok &= get_value(Ttg + 2 * (4 * lane + 3), tag, t3);
-            }
-            if (__all(ok)) break;
-            if (sp.expired(abort_word)) { bad = true; break; }
-        }
-        if (__any(bad)) return false;
-    }
-
+    SSTAMP(0);   // inputs, RNG peek
     int kc = 0;
     double acum_v = 1.0, muk_c = 0.0, denom_c = 1.0;
+    double muk[K], logl[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) { muk[i] = 0.0; logl[i] = 0.0; }
+    const double* denom_g = tab + G + g * K;
     if (use) {
         const double dpa = t0 + t1, dpb = t2 + t3;
         double num = in.msig * (dpa - in.mave * dpb);               // bayes.cpp:765
         num += beta_old * nm1;                                       // bayes.cpp:421
-        decide<K>(num, prob, tab + G + g * K, tab + G + G * K + g * K, tab + G + 2 * G * K + g * K, inv2sige,
-                  kc, acum_v, muk_c, denom_c);
+        acum_v = decide0<K>(num, denom_g, tab + G + G * K + g * K, tab + G + 2 * G * K + g * K, inv2sige, muk, logl);
     }
-    const bool stop = use && (kc > 0 || beta_old != 0.0);
+    SSTAMP(1);   // decide0
+    // a lane whose draw exceeds acum0 ends in a component > 0 (bayes.cpp:451,476): it stops the walk
+    const bool stop = use && (!(prob <= acum_v) || beta_old != 0.0);
     const unsigned long long stop_mask = __ballot(stop);
     const int s = stop_mask ? (__ffsll((long long)stop_mask) - 1) : nb;
     const int n_done = s < nb ? s + 1 : nb;
+    if (s < nb && lane == s && !(prob <= acum_v)) {                 // the component search, one lane
+        decide_rest<K>(prob, acum_v, logl, kc, acum_v);
+#pragma unroll
+        for (int i = 1; i < K; i++)
+            if (i == kc) { muk_c = muk[i]; denom_c = denom_g[i]; }
+    }
 
+    SSTAMP(2);   // component search
     if (act && lane < n_done && lane != s) {
         if (sig0) {
             if (writer) { out.acum[m] = 1.0; out.betas_out[m] = 0.0; }
@@ -293,6 +377,7 @@ __device__ __noinline__ bool sample_batch(int nb, int G, char* smem, const LaneI
         ctl[C_CURSOR] = rs.cursor;
         ctl[C_NDONE] = n_done;
     }
+    SSTAMP(3);   // commit + stop lane
     if (s >= nb && lane == 0) {
         ctl[C_UPD] = 0;
         ctl[C_CURSOR] = cursor0 + __popcll(use_mask);
@@ -306,7 +391,35 @@ __device__ __noinline__ bool sample_batch(int nb, int G, char* smem, const LaneI
         nxt = nxt < SW_GB ? SW_GB : (nxt > SW_BMAX ? SW_BMAX : nxt);
         ctl[C_NBNEXT] = nxt;
     }
-    return true;
+}
+
+// Wavefront 0: lane j polls the totals of batch position j (tagged granules) until they have
+// arrived.  Returns false on timeout.
+__device__ __forceinline__ bool poll_totals(int nb, bool fast, bool act, const unsigned long long* Ttg, unsigned tag,
+                                            double& t0, double& t1, double& t2, double& t3, unsigned* abort_word) {
+    const int lane = threadIdx.x & 63;
+    Spin sp;
+    sp.start();
+    bool bad = false;
+    for (;;) {
+        bool ok = true;
+        if (act) {
+            if (fast) {
+                ok &= get_value(Ttg + 2 * (2 * lane + 0), tag, t0);
+                ok &= get_value(Ttg + 2 * (2 * lane + 1), tag, t1);
+                ok &= get_value(Ttg + 2 * (2 * nb + 0), tag, t2);
+                ok &= get_value(Ttg + 2 * (2 * nb + 1), tag, t3);
+            } else {
+                ok &= get_value(Ttg + 2 * (4 * lane + 0), tag, t0);
+                ok &= get_value(Ttg + 2 * (4 * lane + 1), tag, t1);
+                ok &= get_value(Ttg + 2 * (4 * lane + 2), tag, t2);
+                ok &= get_value(Ttg + 2 * (4 * lane + 3), tag, t3);
+            }
+        }
+        if (__all(ok)) break;
+        if (sp.expired(abort_word)) { bad = true; break; }
+    }
+    return !__any(bad);
 }
 
 // ---- per-R storage types ------------------------------------------------------------------
@@ -335,6 +448,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     const int W = a.W, K = a.K, G = a.G;
 
     double2* lut = reinterpret_cast<double2*>(smem + L_LUT);
+    double* luta = reinterpret_cast<double*>(smem + L_M);    // a per 2-bit code (fast layout)
     const double* s_val = reinterpret_cast<const double*>(smem + L_VAL);
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     uint32_t* s_rng0 = reinterpret_cast<uint32_t*>(smem + L_RNG0);
@@ -348,13 +462,17 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     unsigned long long* Pg = reinterpret_cast<unsigned long long*>(a.P);
     unsigned long long* Ttg = reinterpret_cast<unsigned long long*>(a.Tt);
 
-    if (tid < 4) lut[tid] = make_double2(code_a(tid), code_b(tid));
+    if (tid < 4) { lut[tid] = make_double2(code_a(tid), code_b(tid)); luta[tid] = code_a(tid); }
     for (int i = tid; i < 624; i += SW_TPB) s_rng0[i] = a.rng_state[i];
     for (int i = tid; i < G * K; i += SW_TPB) s_cass[i] = 0;
     for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];   // sigmag|denom|logpi|mhl, contiguous
+#ifdef GM_SWEEP_PROF
+    if (tid < 8) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[tid] = 0ull;
+#endif
     if (tid == 0) {
         ctl[C_CURSOR] = *a.rng_index;
         ctl[C_RNGERR] = 0;
+        ctl[C_BAD] = 0;
         ctl[C_EMA] = 16 * a.batch_init / 2;
         ctl[C_NBNEXT] = a.batch_init;
     }
@@ -374,13 +492,17 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NI; i++) split2(eps[i], q1[i], q2[i]);
+    double sq1 = 0.0, sq2 = 0.0;                     // this thread's sum of q1 / q2 (exact)
+#pragma unroll
+    for (int i = 0; i < NI; i++) { sq1 += q1[i]; sq2 += q2[i]; }
 
     // ---- loader role (wavefronts 1-2): 2R bytes of every upcoming column ----------------
     // codes of NA / out-of-range individuals are forced to 01 (a = b = 0, update value 0)
     const bool loader = wave == 1 || wave == 2;
     const int lt = loader ? tid - 64 : 0;
-    const size_t cb = (size_t)wg * SW_TPB * R + (size_t)lt * 2 * R;
-    const bool lvalid = loader && cb < a.stride;
+    const size_t cb_true = (size_t)wg * SW_TPB * R + (size_t)lt * 2 * R;
+    const bool lvalid = loader && cb_true < a.stride;
+    const size_t cb = lvalid ? cb_true : 0;           // out-of-range lanes read column byte 0 and mask it away
     ld_t lkeep = 0, lforce = ODD;
     if (lvalid) {
         const ld_t nam = *reinterpret_cast<const ld_t*>(a.namask2 + cb);
@@ -396,11 +518,12 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const int n = (to - p0) < PFN ? (to - p0) : PFN;
             if (loader) {
 #pragma unroll
-                for (int i = 0; i < PFN; i++) {
-                    ld_t w = ODD;
-                    if (i < n && lvalid) w = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[p0 + i] * a.stride + cb);
-                    pf[i] = (w & lkeep) | lforce;
+                for (int i = 0; i < PFN; i++) {            // unconditional loads (clamped index): nothing waits on a select
+                    const int pi = p0 + i < a.M ? p0 + i : a.M - 1;
+                    pf[i] = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[pi] * a.stride + cb);
                 }
+#pragma unroll
+                for (int i = 0; i < PFN; i++) pf[i] = (pf[i] & lkeep) | lforce;
 #pragma unroll
                 for (int i = 0; i < PFN; i++)
                     if (i < n) *reinterpret_cast<ld_t*>(ring + (size_t)((p0 + i) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)lt * 2 * R) = pf[i];
@@ -434,50 +557,71 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 
         // wavefront 0: what the sampling step needs about each batch position (overlaps phase A)
         LaneIn li{0, 0, 0.0, 0.0, 1.0};
-        if (wave == 0 && lane < nb) {
-            li.m = a.order[pos + lane];
-            li.g = a.group[li.m];
-            li.beta_old = a.betas_in[li.m];
-            li.mave = a.mave[li.m];
-            li.msig = a.msig[li.m];
+        if (wave == 0) {
+            bool nm = true;
+            if (lane < nb) {
+                li.m = a.order[pos + lane];
+                li.g = a.group[li.m];
+                li.beta_old = a.betas_in[li.m];
+                li.mave = a.mave[li.m];
+                li.msig = a.msig[li.m];
+                nm = a.nomiss[li.m] != 0;
+            }
+            const bool all_nm = __all(nm);
+            if (lane == 0) ctl[C_FAST] = all_nm ? 1 : 0;
         }
         __syncthreads();                              // ring writes of the previous batch are visible
+        const bool fast = ctl[C_FAST] != 0;
         PROF(0);   // batch prologue
 
         // ---- phase A: partial dot products of the batch, genotypes from the ring ----------
-        for (int g0 = 0; g0 < nb; g0 += SW_GB) {
-            double acc[SW_GB * 4];
+        if (fast) {
+            // b == 1 wherever the residual is non-zero: only the a-sums depend on the marker
+            for (int g0 = 0; g0 < nb; g0 += 2 * SW_GB) {
+                double acc[32];
 #pragma unroll
-            for (int gm = 0; gm < SW_GB; gm++) {
-                const int j = g0 + gm;
-                uint32_t wd = 0x55555555u;
-                if (j < nb) wd = *reinterpret_cast<const own_t*>(ring + (size_t)((pos + j) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)tid * R);
-                double sa1 = 0.0, sa2 = 0.0, sb1 = 0.0, sb2 = 0.0;
+                for (int gm = 0; gm < 2 * SW_GB; gm++) {
+                    const int j = g0 + gm;
+                    uint32_t wd = 0x55555555u;
+                    if (j < nb) wd = *reinterpret_cast<const own_t*>(ring + (size_t)((pos + j) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)tid * R);
+                    double sa1 = 0.0, sa2 = 0.0;
 #pragma unroll
-                for (int i = 0; i < NI; i++) {
-                    const double2 ab = lut[(wd >> (2 * i)) & 3u];
-                    sa1 = fma_(ab.x, q1[i], sa1); sa2 = fma_(ab.x, q2[i], sa2);
-                    sb1 = fma_(ab.y, q1[i], sb1); sb2 = fma_(ab.y, q2[i], sb2);
+                    for (int i = 0; i < NI; i++) {
+                        const double av = luta[(wd >> (2 * i)) & 3u];
+                        sa1 = fma_(av, q1[i], sa1); sa2 = fma_(av, q2[i], sa2);
+                    }
+                    acc[gm * 2 + 0] = sa1; acc[gm * 2 + 1] = sa2;
                 }
-                acc[gm * 4 + 0] = sa1; acc[gm * 4 + 1] = sa2; acc[gm * 4 + 2] = sb1; acc[gm * 4 + 3] = sb2;
+                const double r = reduce32(acc, lane);
+                if ((lane & 1) == 0) s_wsum[wave * SW_VMAX + g0 * 2 + (lane >> 1)] = r;
             }
-            // 32 values x 64 lanes -> lane l holds value (l >> 1), summed over the wavefront
+            const double r2 = reduce2(sq1, sq2);
+            if (lane == 0) s_wsum[wave * SW_VMAX + 2 * nb] = r2;
+            if (lane == 32) s_wsum[wave * SW_VMAX + 2 * nb + 1] = r2;
+        } else {
+            for (int g0 = 0; g0 < nb; g0 += SW_GB) {
+                double acc[32];
 #pragma unroll
-            for (int half = 16, mask = 32; half >= 1; half >>= 1, mask >>= 1) {
-                const bool upper = (lane & mask) != 0;
+                for (int gm = 0; gm < SW_GB; gm++) {
+                    const int j = g0 + gm;
+                    uint32_t wd = 0x55555555u;
+                    if (j < nb) wd = *reinterpret_cast<const own_t*>(ring + (size_t)((pos + j) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)tid * R);
+                    double sa1 = 0.0, sa2 = 0.0, sb1 = 0.0, sb2 = 0.0;
 #pragma unroll
-                for (int i = 0; i < half; i++) {
-                    const double send = upper ? acc[i] : acc[i + half];
-                    const double keepv = upper ? acc[i + half] : acc[i];
-                    acc[i] = keepv + __shfl_xor(send, mask, 64);
+                    for (int i = 0; i < NI; i++) {
+                        const double2 ab = lut[(wd >> (2 * i)) & 3u];
+                        sa1 = fma_(ab.x, q1[i], sa1); sa2 = fma_(ab.x, q2[i], sa2);
+                        sb1 = fma_(ab.y, q1[i], sb1); sb2 = fma_(ab.y, q2[i], sb2);
+                    }
+                    acc[gm * 4 + 0] = sa1; acc[gm * 4 + 1] = sa2; acc[gm * 4 + 2] = sb1; acc[gm * 4 + 3] = sb2;
                 }
+                const double r = reduce32(acc, lane);
+                if ((lane & 1) == 0) s_wsum[wave * SW_VMAX + g0 * 4 + (lane >> 1)] = r;
             }
-            acc[0] += __shfl_xor(acc[0], 1, 64);
-            if ((lane & 1) == 0) s_wsum[wave * SW_VMAX + g0 * 4 + (lane >> 1)] = acc[0];
         }
         __syncthreads();
         PROF(1);   // phase A: dots
-        const int nv = nb * 4;
+        const int nv = fast ? 2 * nb + 2 : 4 * nb;
         if (tid < nv) {
             const double tot = s_wsum[tid] + s_wsum[SW_VMAX + tid] + s_wsum[2 * SW_VMAX + tid] + s_wsum[3 * SW_VMAX + tid];
             put_value(Pg + 2 * ((size_t)tid * a.Wpad + wg), tag, tot);
@@ -515,30 +659,36 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (npf < 0) npf = 0;
         if (loader) {
 #pragma unroll
-            for (int i = 0; i < PFN; i++) {
-                ld_t w = ODD;
-                if (i < npf && lvalid) w = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[hi + i] * a.stride + cb);
-                pf[i] = w;
+            for (int i = 0; i < PFN; i++) {                // unconditional loads (clamped index), consumed at the ring write
+                const int pi = hi + i < a.M ? hi + i : a.M - 1;
+                pf[i] = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[pi] * a.stride + cb);
             }
         }
 
         // ---- sampling step (wavefront 0, every workgroup, identical inputs) -------------
         if (wave == 0) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
-            bool okw = true;
-            switch (K) {
-                case 2: okw = sample_batch<2>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
-                case 3: okw = sample_batch<3>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
-                case 4: okw = sample_batch<4>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
-                case 5: okw = sample_batch<5>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
-                case 6: okw = sample_batch<6>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
-                case 7: okw = sample_batch<7>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
-                default: okw = sample_batch<8>(nb, G, smem, li, Ttg, tag, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, abort_word); break;
-            }
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            const bool okw = poll_totals(nb, fast, lane < nb, Ttg, tag, t0, t1, t2, t3, abort_word);
+            PROF(4);   // wait for the totals
             bad |= !okw;
+            if (okw) {
+                switch (K) {
+                    case 2: sample_batch<2>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 3: sample_batch<3>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 4: sample_batch<4>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 5: sample_batch<5>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 6: sample_batch<6>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 7: sample_batch<7>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    default: sample_batch<8>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                }
+            }
         }
-        if (__syncthreads_or(bad ? 1 : 0) || ctl[C_RNGERR]) { ok = false; break; }
-        PROF(5);   // wait for the totals + sampling step
+        PROF(7);   // sampling step incl. call overhead (wavefront 0's own time)
+        if (bad) ctl[C_BAD] = 1;
+        lds_barrier();                                // no vmcnt drain: prefetches stay in flight
+        if (ctl[C_BAD] || ctl[C_RNGERR]) { ok = false; break; }
+        PROF(5);   // barrier after sampling (waiting for the other wavefronts)
 
         // ---- phase C: residual update of the stopping marker (its slice is in the ring) ----
         if (ctl[C_UPD]) {
@@ -549,6 +699,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 eps[i] += s_val[(wd >> (2 * i)) & 3u];
                 split2(eps[i], q1[i], q2[i]);
             }
+            sq1 = 0.0; sq2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NI; i++) { sq1 += q1[i]; sq2 += q2[i]; }
         }
         // ---- loaders: park the fetched slices in the ring (visible after the next barrier) --
         if (loader) {
@@ -585,8 +738,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
     }
 #ifdef GM_SWEEP_PROF
-    if (tid == 0 && (wg == 0 || wg == W / 2))
+    if (tid == 0 && (wg == 0 || wg == W / 2)) {
         for (int i = 0; i < 8; i++) a.stats[(wg == 0 ? 4 : 12) + i] = (long long)prof[i];
+        if (wg != 0) for (int i = 0; i < 4; i++) a.stats[20 + i] = (long long)reinterpret_cast<unsigned long long*>(smem + L_M + 64)[i];
+    }
 #endif
 }
 
