@@ -104,8 +104,8 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
         HIPCHK(dalloc(&tr.cass, (size_t)GMAX * KMAX));
         HIPCHK(dalloc(&tr.stats, (size_t)24));
         HIPCHK(dalloc(&tr.err, (size_t)4));
-        HIPCHK(dalloc(&tr.P, (size_t)2 * SW_VMAX * c->Wpad));       // two 8-byte granules per value
-        HIPCHK(dalloc(&tr.Tt, (size_t)2 * SW_VMAX));
+        HIPCHK(dalloc(&tr.P, (size_t)4 * SW_VMAX * c->Wpad));       // 2 generations x two 8-byte granules per value
+        HIPCHK(dalloc(&tr.Tt, (size_t)4 * SW_VMAX));
         HIPCHK(dalloc(&tr.cnt, (size_t)96));
         HIPCHK(dalloc(&tr.scratch, (size_t)8));
         HIPCHK(hipStreamCreateWithFlags(&tr.stream, hipStreamNonBlocking));
@@ -253,6 +253,12 @@ int gmrm_marker_stats(gmrm_ctx* c, int t) {
     Trait& tr = c->tr[t];
     HIPCHK(launch_marker_stats(c->bed, tr.namask2, c->stride, c->M, tr.nonas, tr.mave, tr.msig, tr.nomiss, tr.stream));
     HIPCHK(hipStreamSynchronize(tr.stream));
+    {   // one flag per block: can the sweep use the 2-value exchange layout?
+        std::vector<uint8_t> nm((size_t)c->M);
+        if (c->M > 0) HIPCHK(hipMemcpy(nm.data(), tr.nomiss, (size_t)c->M, hipMemcpyDeviceToHost));
+        tr.all_nomiss = 1;
+        for (uint8_t v : nm) if (!v) { tr.all_nomiss = 0; break; }
+    }
     tr.have_stats = true;
     return GMRM_OK;
 }
@@ -273,6 +279,7 @@ int gmrm_set_marker_stats(gmrm_ctx* c, int t, const double* mave, const double* 
     HIPCHK(hipMemcpy(c->tr[t].mave, mave, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->tr[t].msig, msig, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(c->tr[t].nomiss, 0, (size_t)(c->M > 0 ? c->M : 1)));   // unknown: general exchange layout
+    c->tr[t].all_nomiss = 0;
     c->tr[t].have_stats = true;
     return GMRM_OK;
 }
@@ -401,8 +408,8 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     HIPCHK(hipMemcpyAsync(tr.rng_index, &in->rng_index, sizeof(int), hipMemcpyHostToDevice, tr.stream));
     // every polled word starts at zero in every launch (tags count from 1 inside the launch)
     HIPCHK(hipMemsetAsync(tr.cnt, 0, 96 * sizeof(unsigned), tr.stream));
-    HIPCHK(hipMemsetAsync(tr.P, 0, (size_t)2 * SW_VMAX * c->Wpad * sizeof(double), tr.stream));
-    HIPCHK(hipMemsetAsync(tr.Tt, 0, (size_t)2 * SW_VMAX * sizeof(double), tr.stream));
+    HIPCHK(hipMemsetAsync(tr.P, 0, (size_t)4 * SW_VMAX * c->Wpad * sizeof(double), tr.stream));
+    HIPCHK(hipMemsetAsync(tr.Tt, 0, (size_t)4 * SW_VMAX * sizeof(double), tr.stream));
     HIPCHK(hipMemsetAsync(tr.err, 0, 4 * sizeof(int), tr.stream));
     HIPCHK(hipMemsetAsync(tr.stats, 0, 24 * sizeof(long long), tr.stream));
 
@@ -421,6 +428,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.cass = tr.cass; a.stats = tr.stats; a.err = tr.err;
     a.P = tr.P; a.Tt = tr.Tt; a.cnt = tr.cnt;
     a.batch_init = c->batch_init;
+    a.all_nomiss = tr.all_nomiss;
     // Phenotypes that do not fit side by side share stream 0 and run one after another.
     hipStream_t st = c->concurrent ? tr.stream : c->tr[0].stream;
     if (!c->concurrent && t != 0) HIPCHK(hipStreamSynchronize(tr.stream));   // uploads above done
@@ -454,9 +462,9 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
         HIPCHK(hipMemcpy(st, tr.stats, sizeof(st), hipMemcpyDeviceToHost));
         out->n_updates = st[0]; out->n_batches = st[1];
         if (std::getenv("GMRM_SWEEP_PROF")) {                  // diagnostic build only (-DGM_SWEEP_PROF)
-            static const char* nm[8] = {"prologue", "dots", "publish", "reduce", "wait_totals", "post_barrier", "update", "sample"};
+            static const char* nm[8] = {"promote+reduce", "spec_dots", "pf_issue", "-", "wait_totals", "post_barrier", "update", "sample"};
             for (int w = 0; w < 2; w++) {
-                std::fprintf(stderr, "[sweep prof wg %s] batches %lld:", w ? "W/2" : "0", st[1]);
+                std::fprintf(stderr, "[sweep prof wg %s] batches %lld (discarded %lld):", w ? "W/2" : "0", st[1], st[3]);
                 for (int i = 0; i < 8; i++)
                     std::fprintf(stderr, " %s %.2fus", nm[i], st[1] ? st[(w ? 12 : 4) + i] * 0.01 / (double)st[1] : 0.0);
                 std::fprintf(stderr, "\n");

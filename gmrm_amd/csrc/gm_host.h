@@ -23,6 +23,7 @@ struct Trait {
     double* acum = nullptr;         // Phenotype::acum [M]
     int nonas = 0;
     bool have_trait = false, have_stats = false, in_flight = false, empty = false;
+    int all_nomiss = 0;             // every marker of the block: nomiss == 1
     int G = 0, K = 0;
     // sweep workspace
     int* order = nullptr;

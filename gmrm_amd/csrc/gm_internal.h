@@ -45,6 +45,7 @@ struct SweepArgs {
     double* Tt;                    // [SW_VMAX] totals
     unsigned* cnt;                 // [96] arrival counters / abort word, zeroed per launch
     int batch_init;
+    int all_nomiss;                // 1: no marker of this block has a missing genotype among the phenotyped individuals
 };
 
 // sweep.hip

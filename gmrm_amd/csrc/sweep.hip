@@ -40,7 +40,8 @@
 namespace gm {
 
 // ---- LDS carve (bytes, all multiples of 16) --------------------------------------------
-constexpr int RING_POS = 128;                   // ring capacity in order positions (2 * SW_BMAX)
+constexpr int ring_pos(int R) { return R == 4 ? 128 : 256; }   // ring capacity in order positions
+constexpr int bmax(int R) { return R == 4 ? 32 : 64; }          // markers per batch (two batches + look-ahead fit the ring)
 constexpr int PFN      = 24;                    // positions prefetched per batch per loader thread
 constexpr int L_LUT  = 0;                       // double2[4]   (a,b) per 2-bit code
 constexpr int L_VAL  = 64;                      // double[4]    update table of the stopping marker
@@ -52,11 +53,13 @@ constexpr int L_CASS = L_RNG1 + 2496;           // int[GMAX*KMAX]
 constexpr int L_WSUM = L_CASS + GMAX * KMAX * 4;   // double[4][SW_VMAX]
 constexpr int L_RED  = L_WSUM + 4 * SW_VMAX * 8;   // double[4]
 constexpr int L_TAB  = L_RED + 64;                 // double[GMAX*(1+3*KMAX)] per-group tables
-constexpr int L_RING = L_TAB + GMAX * (1 + 3 * KMAX) * 8;   // uint8[RING_POS][SW_TPB*R]
+constexpr int META_POS = 128;                   // per-marker inputs of the sampling step, ring over order positions
+constexpr int L_META = L_TAB + GMAX * (1 + 3 * KMAX) * 8;   // int m[128], int g[128], double beta[128], mave[128], msig[128]
+constexpr int L_RING = L_META + META_POS * 32;              // uint8[ring_pos(R)][SW_TPB*R]
 static_assert(L_RING % 16 == 0, "LDS carve");
 // Request > 80 KiB so that exactly one workgroup fits per CU.
 constexpr int L_MIN = 84 * 1024;
-constexpr int lds_total(int R) { return (L_RING + RING_POS * SW_TPB * R) > L_MIN ? (L_RING + RING_POS * SW_TPB * R) : L_MIN; }
+constexpr int lds_total(int R) { return (L_RING + ring_pos(R) * SW_TPB * R) > L_MIN ? (L_RING + ring_pos(R) * SW_TPB * R) : L_MIN; }
 static_assert(lds_total(4) <= 160 * 1024, "LDS budget");
 
 enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_FAST, C_BAD };
@@ -112,6 +115,20 @@ constexpr int DPP_ROW_MIRROR = 0x140;        // lane ^ 15 within a row of 16
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;   // lane ^ 7
 constexpr int DPP_QUAD_3210 = 0x1B;          // lane ^ 3
 constexpr int DPP_QUAD_1032 = 0xB1;          // lane ^ 1
+
+// Genotype decode without a table read (an LDS read per individual costs ~70 exposed cycles at
+// one wavefront per SIMD): a = {2,0,1,0}[c], b = {1,0,1,1}[c] as IEEE doubles built from the code
+// bits -- high word 0x40000000 - (h << 20) masked by !l for a, 0x3FF00000 masked by !(l & !h) for b.
+// The values are those of the reference's dotp_lut_a / dotp_lut_b rows (src/dotp_lut.hpp).
+__device__ __forceinline__ double code_a_bits(uint32_t w, uint32_t nw, int i) {
+    const uint32_t h = (w >> (2 * i + 1)) & 1u;
+    const uint32_t nl = (uint32_t)((int)(nw << (31 - 2 * i)) >> 31);        // all ones when the low bit is 0
+    return mk64(0u, (0x40000000u - (h << 20)) & nl);
+}
+__device__ __forceinline__ double code_b_bits(uint32_t present, int i) {   // present: bit 2i set unless code == 01
+    const uint32_t pm = (uint32_t)((int)(present << (31 - 2 * i)) >> 31);
+    return mk64(0u, 0x3FF00000u & pm);
+}
 
 // 32 per-lane values -> lane l holds value (l >> 1) summed over the 64 lanes.  Each step pairs
 // lanes that agree on every earlier selector bit (masks 32, 16, 15, 7, 3, then 1), so the sums
@@ -294,7 +311,7 @@ struct SampleOut {                 // global outputs, written by workgroup 0 onl
 #endif
 
 template <int K>
-__device__ __noinline__ void sample_batch(int nb, int G, char* smem, const LaneIn in, double t0, double t1,
+__device__ __noinline__ void sample_batch(int nb, int bmax_, int gran, int G, char* smem, const LaneIn in, double t0, double t1,
                                           double t2, double t3, double sigmae, double inv2sige, double nm1,
                                           const SampleOut out, bool writer) {
     const int lane = threadIdx.x & 63;
@@ -387,8 +404,8 @@ __device__ __noinline__ void sample_batch(int nb, int G, char* smem, const LaneI
         const int run = s < nb ? s + 1 : 2 * nb;
         const int ema = (3 * ctl[C_EMA] + 16 * run) / 4;            // fixed point, 1/16 marker
         ctl[C_EMA] = ema;
-        int nxt = ((2 * ema / 16) + SW_GB - 1) / SW_GB * SW_GB;
-        nxt = nxt < SW_GB ? SW_GB : (nxt > SW_BMAX ? SW_BMAX : nxt);
+        int nxt = ((2 * ema / 16) + gran - 1) / gran * gran;       // whole register groups only
+        nxt = nxt < gran ? gran : (nxt > bmax_ ? bmax_ : nxt);
         ctl[C_NBNEXT] = nxt;
     }
 }
@@ -444,6 +461,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     using ld_t = typename Slice<R>::ld_t;            // a loader thread's 2R bytes
     constexpr int NI = 4 * R;                        // individuals per thread
     constexpr ld_t ODD = (ld_t)0x5555555555555555ull;
+    constexpr int RPOS = ring_pos(R), BMAX = bmax(R);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
     const int W = a.W, K = a.K, G = a.G;
 
@@ -526,68 +544,124 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 for (int i = 0; i < PFN; i++) pf[i] = (pf[i] & lkeep) | lforce;
 #pragma unroll
                 for (int i = 0; i < PFN; i++)
-                    if (i < n) *reinterpret_cast<ld_t*>(ring + (size_t)((p0 + i) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)lt * 2 * R) = pf[i];
+                    if (i < n) *reinterpret_cast<ld_t*>(ring + (size_t)((p0 + i) & (RPOS - 1)) * (SW_TPB * R) + (size_t)lt * 2 * R) = pf[i];
             }
         }
         __syncthreads();
     };
 
+    // ---- per-marker inputs of the sampling step (marker id, group, previous effect, mave, msig):
+    // wavefront 3 fetches them for upcoming order positions (dependent global loads) one
+    // iteration ahead and parks them in a 128-position LDS ring, so a restart never waits on them.
+    int* mr_m = reinterpret_cast<int*>(smem + L_META);
+    int* mr_g = mr_m + META_POS;
+    double* mr_beta = reinterpret_cast<double*>(mr_g + META_POS);
+    double* mr_mave = mr_beta + META_POS;
+    double* mr_msig = mr_mave + META_POS;
+    int mhi = 0, npm = 0;                             // meta ring holds positions [pos, mhi)
+    int pm_m = 0, pm_g = 0;
+    double pm_beta = 0.0, pm_mave = 0.0, pm_msig = 1.0;
+    auto meta_issue = [&](int base_pos) {
+        int want = base_pos + META_POS < a.M ? base_pos + META_POS : a.M;
+        npm = want - mhi;
+        if (npm > 64) npm = 64;
+        if (npm < 0) npm = 0;
+        if (wave == 3) {
+            const int pi = mhi + lane < a.M ? mhi + lane : a.M - 1;
+            pm_m = a.order[pi];
+            pm_g = a.group[pm_m];
+            pm_beta = a.betas_in[pm_m];
+            pm_mave = a.mave[pm_m];
+            pm_msig = a.msig[pm_m];
+        }
+    };
+    auto meta_commit = [&]() {
+        if (wave == 3 && lane < npm) {
+            const int sl = (mhi + lane) & (META_POS - 1);
+            mr_m[sl] = pm_m; mr_g[sl] = pm_g; mr_beta[sl] = pm_beta; mr_mave[sl] = pm_mave; mr_msig[sl] = pm_msig;
+        }
+        mhi += npm;
+        npm = 0;
+    };
+    auto ensure_meta = [&](int base_pos, int upto) {   // slow path (uniform): meta ring must hold [.., upto)
+        if (mhi < upto) meta_commit();
+        while (mhi < upto) { meta_issue(base_pos); meta_commit(); }
+    };
+
+    // ---- the marker loop, software-pipelined over exchange generations -----------------------
+    // While the totals of the current batch are in flight, every wavefront already computes
+    // and publishes the dots of the NEXT batch, assuming the current one ends without a residual
+    // update.  If it does end that way the next batch is promoted (its partials are already at
+    // the reducers); otherwise it is discarded and a fresh batch starts after the stopping
+    // marker.  Generation g uses tag g+1 and buffer g&1; a buffer is rewritten only after every
+    // workgroup has sampled the generation that used it.
+    struct Batch { int p0, nb, nv; unsigned gen; bool fast; };
     int pos = 0;
-    unsigned gen = 0;
-    long long n_upd = 0, n_batch = 0;
+    unsigned gen_next = 0;
+    long long n_upd = 0, n_batch = 0, n_disc = 0;
     int max_nb = 0;
     bool ok = true;
 #ifdef GM_SWEEP_PROF
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memrealtime();
 #endif
-    {
-        const int first = a.batch_init + SW_BMAX < a.M ? a.batch_init + SW_BMAX : a.M;
-        fill(0, first);
-        hi = first;
-    }
+    int npf = 0;
 
-    while (pos < a.M) {
-        if (ctl[C_CURSOR] >= 624) block_advance(s_rng0, s_rng1, ctl, true);
-        int nb = ctl[C_NBNEXT];
-        if (nb > a.M - pos) nb = a.M - pos;
-        max_nb = nb > max_nb ? nb : max_nb;
-        if (hi < pos + nb) { fill(hi, pos + nb); hi = pos + nb; }    // slow path (uniform)
-        const unsigned tag = gen + 1u;
-
-        // wavefront 0: what the sampling step needs about each batch position (overlaps phase A)
-        LaneIn li{0, 0, 0.0, 0.0, 1.0};
-        if (wave == 0) {
-            bool nm = true;
-            if (lane < nb) {
-                li.m = a.order[pos + lane];
-                li.g = a.group[li.m];
-                li.beta_old = a.betas_in[li.m];
-                li.mave = a.mave[li.m];
-                li.msig = a.msig[li.m];
-                nm = a.nomiss[li.m] != 0;
+    auto prefetch_issue = [&](int limit) {
+        int want = limit < a.M ? limit : a.M;
+        if (want > pos + RPOS) want = pos + RPOS;
+        npf = want - hi;
+        if (npf > PFN) npf = PFN;
+        if (npf < 0) npf = 0;
+        if (loader) {
+#pragma unroll
+            for (int i = 0; i < PFN; i++) {                // unconditional loads (clamped index), consumed at the ring write
+                const int pi = hi + i < a.M ? hi + i : a.M - 1;
+                pf[i] = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[pi] * a.stride + cb);
             }
-            const bool all_nm = __all(nm);
-            if (lane == 0) ctl[C_FAST] = all_nm ? 1 : 0;
         }
-        __syncthreads();                              // ring writes of the previous batch are visible
-        const bool fast = ctl[C_FAST] != 0;
-        PROF(0);   // batch prologue
+    };
+    // park the slices fetched by the previous prefetch_issue in the ring (readers see them after
+    // the next barrier).  Called late -- right before the next issue -- so nobody waits for HBM.
+    auto prefetch_commit = [&]() {
+        if (loader) {
+#pragma unroll
+            for (int i = 0; i < PFN; i++)
+                if (i < npf) *reinterpret_cast<ld_t*>(ring + (size_t)((hi + i) & (RPOS - 1)) * (SW_TPB * R) + (size_t)lt * 2 * R) = (pf[i] & lkeep) | lforce;
+        }
+        hi += npf;
+        npf = 0;
+    };
+    auto ensure = [&](int upto) {                      // slow path: ring must hold [pos, upto)
+        if (hi < upto) prefetch_commit();
+        if (hi < upto) { fill(hi, upto); hi = upto; }
+    };
 
-        // ---- phase A: partial dot products of the batch, genotypes from the ring ----------
+    // phase A for positions [b.p0, b.p0 + b.nb) (slices already in the ring) + publish
+    auto compute_publish = [&](Batch& b, LaneIn& li) {
+        lds_barrier();                                // ring writes are visible (no vmcnt drain)
+        li = LaneIn{0, 0, 0.0, 0.0, 1.0};
+        if (wave == 0 && lane < b.nb) {
+            const int sl = (b.p0 + lane) & (META_POS - 1);
+            li.m = mr_m[sl]; li.g = mr_g[sl]; li.beta_old = mr_beta[sl]; li.mave = mr_mave[sl]; li.msig = mr_msig[sl];
+        }
+        const bool fast = a.all_nomiss != 0;          // exchange layout, fixed per launch
+        const int nb = b.nb, p0 = b.p0;
+        max_nb = nb > max_nb ? nb : max_nb;
         if (fast) {
             // b == 1 wherever the residual is non-zero: only the a-sums depend on the marker
             for (int g0 = 0; g0 < nb; g0 += 2 * SW_GB) {
                 double acc[32];
 #pragma unroll
                 for (int gm = 0; gm < 2 * SW_GB; gm++) {
-                    const int j = g0 + gm;
-                    uint32_t wd = 0x55555555u;
-                    if (j < nb) wd = *reinterpret_cast<const own_t*>(ring + (size_t)((pos + j) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)tid * R);
+                    // unconditional ring read: slots past the batch hold finite junk that nobody consumes
+                    const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((p0 + g0 + gm) & (RPOS - 1)) * (SW_TPB * R) + (size_t)tid * R);
                     double sa1 = 0.0, sa2 = 0.0;
 #pragma unroll
+                    const uint32_t nw = ~wd;
+#pragma unroll
                     for (int i = 0; i < NI; i++) {
-                        const double av = luta[(wd >> (2 * i)) & 3u];
+                        const double av = code_a_bits(wd, nw, i);
                         sa1 = fma_(av, q1[i], sa1); sa2 = fma_(av, q2[i], sa2);
                     }
                     acc[gm * 2 + 0] = sa1; acc[gm * 2 + 1] = sa2;
@@ -603,15 +677,16 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 double acc[32];
 #pragma unroll
                 for (int gm = 0; gm < SW_GB; gm++) {
-                    const int j = g0 + gm;
-                    uint32_t wd = 0x55555555u;
-                    if (j < nb) wd = *reinterpret_cast<const own_t*>(ring + (size_t)((pos + j) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)tid * R);
+                    const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((p0 + g0 + gm) & (RPOS - 1)) * (SW_TPB * R) + (size_t)tid * R);
                     double sa1 = 0.0, sa2 = 0.0, sb1 = 0.0, sb2 = 0.0;
 #pragma unroll
+                    const uint32_t nw = ~wd;
+                    const uint32_t present = ~(wd & ~(wd >> 1));               // bit 2i clear only for code 01
+#pragma unroll
                     for (int i = 0; i < NI; i++) {
-                        const double2 ab = lut[(wd >> (2 * i)) & 3u];
-                        sa1 = fma_(ab.x, q1[i], sa1); sa2 = fma_(ab.x, q2[i], sa2);
-                        sb1 = fma_(ab.y, q1[i], sb1); sb2 = fma_(ab.y, q2[i], sb2);
+                        const double av = code_a_bits(wd, nw, i), bv = code_b_bits(present, i);
+                        sa1 = fma_(av, q1[i], sa1); sa2 = fma_(av, q2[i], sa2);
+                        sb1 = fma_(bv, q1[i], sb1); sb2 = fma_(bv, q2[i], sb2);
                     }
                     acc[gm * 4 + 0] = sa1; acc[gm * 4 + 1] = sa2; acc[gm * 4 + 2] = sb1; acc[gm * 4 + 3] = sb2;
                 }
@@ -620,80 +695,126 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             }
         }
         __syncthreads();
-        PROF(1);   // phase A: dots
         const int nv = fast ? 2 * nb + 2 : 4 * nb;
         if (tid < nv) {
             const double tot = s_wsum[tid] + s_wsum[SW_VMAX + tid] + s_wsum[2 * SW_VMAX + tid] + s_wsum[3 * SW_VMAX + tid];
-            put_value(Pg + 2 * ((size_t)tid * a.Wpad + wg), tag, tot);
+            put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)tid * a.Wpad + wg), b.gen + 1u, tot);
         }
-        PROF(2);   // publish partials
+        b.fast = fast;
+        b.nv = nv;
+    };
 
-        // ---- reduce role: workgroup v sums row v over all workgroups ---------------------
+    // reduce role: workgroup v sums row v of generation b.gen over all workgroups
+    auto reduce_role = [&](const Batch& b) -> bool {
         bool bad = false;
-        if (wg < nv) {
-            for (int v = wg; v < nv; v += W) {
+        if (wg < b.nv) {
+            const unsigned long long* Pb = Pg + 2 * (size_t)(b.gen & 1u) * SW_VMAX * a.Wpad;
+            unsigned long long* Tb = Ttg + 2 * (size_t)(b.gen & 1u) * SW_VMAX;
+            for (int v = wg; v < b.nv; v += W) {
                 double x = 0.0;
                 if (tid < W) {
                     Spin sp;
                     sp.start();
-                    const unsigned long long* gp = Pg + 2 * ((size_t)v * a.Wpad + tid);
-                    while (!get_value(gp, tag, x)) {
+                    const unsigned long long* gp = Pb + 2 * ((size_t)v * a.Wpad + tid);
+                    while (!get_value(gp, b.gen + 1u, x)) {
                         if (sp.expired(abort_word)) { bad = true; x = 0.0; break; }
                     }
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
                 if (lane == 0) s_red[wave] = x;
-                __syncthreads();
-                if (tid == 0) put_value(Ttg + 2 * v, tag, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
-                __syncthreads();
+                lds_barrier();
+                if (tid == 0) put_value(Tb + 2 * v, b.gen + 1u, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+                lds_barrier();
             }
         }
-        PROF(3);   // reduce role
+        return bad;
+    };
 
-        // ---- loaders: fetch the column slices of upcoming positions (overlaps the exchange)
-        int want = pos + nb + SW_BMAX;
-        if (want > a.M) want = a.M;
-        int npf = want - hi;
-        if (npf > PFN) npf = PFN;
-        if (npf < 0) npf = 0;
-        if (loader) {
-#pragma unroll
-            for (int i = 0; i < PFN; i++) {                // unconditional loads (clamped index), consumed at the ring write
-                const int pi = hi + i < a.M ? hi + i : a.M - 1;
-                pf[i] = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[pi] * a.stride + cb);
+    Batch cur{0, 0, 0, 0u, false}, nxt{0, 0, 0, 0u, false}, tb{0, 0, 0, 0u, false};
+    LaneIn li_cur{0, 0, 0.0, 0.0, 1.0}, li_nxt{0, 0, 0.0, 0.0, 1.0}, tl{0, 0, 0.0, 0.0, 1.0};
+    bool bad = false;
+    {
+        int first = 3 * BMAX < a.M ? 3 * BMAX : a.M;
+        if (first > RPOS) first = RPOS;
+        fill(0, first);
+        hi = first;
+        ensure_meta(0, META_POS < a.M ? META_POS : a.M);
+        __syncthreads();
+    }
+    // One compute site and one reduce site serve the three cases (first batch, restart after a
+    // residual update, speculative next batch); `restart` / `need_reduce` select the case.
+    bool restart = true, need_reduce = false, have_next = false;
+    while (pos < a.M) {
+        if (need_reduce) { bad = reduce_role(cur); need_reduce = false; }
+        PROF(0);   // reduce role
+        bool do_compute = false;
+        if (restart) {
+            int nb0 = ctl[C_NBNEXT];
+            if (nb0 > a.M - pos) nb0 = a.M - pos;
+            tb.p0 = pos; tb.nb = nb0; tb.gen = gen_next++;
+            do_compute = true;
+        } else if (ctl[C_EMA] >= 24 * cur.nb) {       // speculate only when the recent run length (1/16 units)
+            const int p1 = pos + cur.nb;              // is >= 1.5 batches: P(no residual update) >~ 1/2
+            if (p1 < a.M) {
+                int nb1 = ctl[C_NBNEXT];
+                if (nb1 > a.M - p1) nb1 = a.M - p1;
+                tb.p0 = p1; tb.nb = nb1; tb.gen = gen_next++;
+                do_compute = true;
             }
         }
+        if (do_compute) {
+            ensure(tb.p0 + tb.nb);
+            ensure_meta(pos, tb.p0 + tb.nb);
+            compute_publish(tb, tl);
+        }
+        PROF(1);   // dots + publish (restart: on the critical path; speculative: overlaps the exchange)
+        if (restart) {
+            cur = tb; li_cur = tl;
+            restart = false;
+            need_reduce = true;
+            continue;
+        }
+        have_next = do_compute;
+        if (have_next) { nxt = tb; li_nxt = tl; }
+        prefetch_commit();
+        meta_commit();
+        prefetch_issue(pos + cur.nb + (have_next ? nxt.nb : 0) + BMAX);
+        meta_issue(pos);
+        PROF(2);   // ring write of the previous prefetch + issue of the next
 
-        // ---- sampling step (wavefront 0, every workgroup, identical inputs) -------------
+        // ---- sampling step of the current batch (wavefront 0, every workgroup, identical inputs)
         if (wave == 0) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
+            const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
             double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-            const bool okw = poll_totals(nb, fast, lane < nb, Ttg, tag, t0, t1, t2, t3, abort_word);
+            const bool okw = poll_totals(cur.nb, cur.fast, lane < cur.nb, Tb, cur.gen + 1u, t0, t1, t2, t3, abort_word);
             PROF(4);   // wait for the totals
             bad |= !okw;
             if (okw) {
                 switch (K) {
-                    case 2: sample_batch<2>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 3: sample_batch<3>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 4: sample_batch<4>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 5: sample_batch<5>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 6: sample_batch<6>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 7: sample_batch<7>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    default: sample_batch<8>(nb, G, smem, li, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 2: sample_batch<2>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 3: sample_batch<3>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 4: sample_batch<4>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 5: sample_batch<5>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 6: sample_batch<6>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 7: sample_batch<7>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    default: sample_batch<8>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
                 }
             }
         }
-        PROF(7);   // sampling step incl. call overhead (wavefront 0's own time)
+        PROF(7);   // sampling step (wavefront 0's own time)
         if (bad) ctl[C_BAD] = 1;
         lds_barrier();                                // no vmcnt drain: prefetches stay in flight
         if (ctl[C_BAD] || ctl[C_RNGERR]) { ok = false; break; }
-        PROF(5);   // barrier after sampling (waiting for the other wavefronts)
+        PROF(5);   // barrier after sampling
 
         // ---- phase C: residual update of the stopping marker (its slice is in the ring) ----
-        if (ctl[C_UPD]) {
+        const int n_done = ctl[C_NDONE];
+        const bool upd = ctl[C_UPD] != 0;
+        if (upd) {
             n_upd++;
-            const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((pos + ctl[C_SUPD]) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)tid * R);
+            const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((pos + ctl[C_SUPD]) & (RPOS - 1)) * (SW_TPB * R) + (size_t)tid * R);
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 eps[i] += s_val[(wd >> (2 * i)) & 3u];
@@ -703,17 +824,18 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #pragma unroll
             for (int i = 0; i < NI; i++) { sq1 += q1[i]; sq2 += q2[i]; }
         }
-        // ---- loaders: park the fetched slices in the ring (visible after the next barrier) --
-        if (loader) {
-#pragma unroll
-            for (int i = 0; i < PFN; i++)
-                if (i < npf) *reinterpret_cast<ld_t*>(ring + (size_t)((hi + i) & (RING_POS - 1)) * (SW_TPB * R) + (size_t)lt * 2 * R) = (pf[i] & lkeep) | lforce;
-        }
-        hi += npf;
-        pos += ctl[C_NDONE];
-        gen++;
+        pos += n_done;
         n_batch++;
         PROF(6);   // residual update + ring write
+        if (ctl[C_CURSOR] >= 624) block_advance(s_rng0, s_rng1, ctl, true);
+        if (upd || n_done < cur.nb || !have_next) {   // the speculative batch (if any) is stale: restart
+            if (have_next) n_disc++;
+            restart = true;
+        } else {                                      // promote: its partials are already at the reducers
+            cur = nxt;
+            li_cur = li_nxt;
+            need_reduce = true;
+        }
     }
 
     if (!ok) {
@@ -734,7 +856,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         for (int i = tid; i < G * K; i += SW_TPB) a.cass[i] = s_cass[i];
         if (tid == 0) {
             *a.rng_index = ctl[C_CURSOR];
-            a.stats[0] = n_upd; a.stats[1] = n_batch; a.stats[2] = max_nb; a.stats[3] = 0;
+            a.stats[0] = n_upd; a.stats[1] = n_batch; a.stats[2] = max_nb; a.stats[3] = n_disc;
         }
     }
 #ifdef GM_SWEEP_PROF
