@@ -657,7 +657,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     // unconditional ring read: slots past the batch hold finite junk that nobody consumes
                     const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((p0 + g0 + gm) & (RPOS - 1)) * (SW_TPB * R) + (size_t)tid * R);
                     double sa1 = 0.0, sa2 = 0.0;
-#pragma unroll
                     const uint32_t nw = ~wd;
 #pragma unroll
                     for (int i = 0; i < NI; i++) {
@@ -679,7 +678,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 for (int gm = 0; gm < SW_GB; gm++) {
                     const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((p0 + g0 + gm) & (RPOS - 1)) * (SW_TPB * R) + (size_t)tid * R);
                     double sa1 = 0.0, sa2 = 0.0, sb1 = 0.0, sb2 = 0.0;
-#pragma unroll
                     const uint32_t nw = ~wd;
                     const uint32_t present = ~(wd & ~(wd >> 1));               // bit 2i clear only for code 01
 #pragma unroll
