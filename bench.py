@@ -178,6 +178,15 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (it cannot
+        # be read inside this process); the committed summary of the same workload is quoted.
+        traffic = None
+        pmc = ROOT / "profiles" / "r01_v26_pmc_summary.json"
+        if pmc.exists() and a.workload == "c3" and world == 1 and not a.markers and not a.individuals:
+            try:
+                traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_k_sweep"]
+            except Exception:
+                traffic = None
         mbytes = ctx.mbytes
         value = Mt * T * a.steps / dt
         avg_kernel_s = (sum(kern_ms) / len(kern_ms)) / 1e3
@@ -193,7 +202,9 @@ def main():
                        "markers_per_gpu": M, "parallelism": f"marker-shard x{world}, 1 residual all-reduce/sweep",
                        "phenotype_na_rate": na_rate, "genotype_missing_rate": miss},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": "bytes per launch: raw FETCH_SIZE + WRITE_SIZE from profiles/r01_v26_pmc_summary.json "
+                                         "(separate rocprofv3 --pmc passes of this workload)" if traffic else None,
                          "kernel": "gm::k_sweep (persistent marker loop)",
                          "kernel_ms_avg": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes},
