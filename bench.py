@@ -111,7 +111,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_pg = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ     # also under torchrun with 1 rank
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -141,7 +142,7 @@ def main():
     cva = np.tile(base, (G, 1))
     group_index = (np.arange(Mt) % G).astype(np.int32)
     smp = gmrm_amd.Sampler(ctx, a.seed, cva, group_index, rank=rank, nranks=world)
-    driver = ShardedDriver(HipEngine(smp, dev)) if world > 1 else None
+    driver = ShardedDriver(HipEngine(smp, dev)) if use_pg else None
     t_setup = time.perf_counter() - t_setup
 
     def step(it):
@@ -151,7 +152,7 @@ def main():
             smp.iterate(it)
 
     def fence():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
         lib.gmrm_ctx_sync(ctx.h)
@@ -172,7 +173,7 @@ def main():
         batches.append(hy.n_batches)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -224,7 +225,7 @@ def main():
         print(json.dumps(out), flush=True)
     smp.close()
     ctx.close()
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -87,10 +87,11 @@ class ShardedDriver:
         dist.broadcast(mu, src=0, group=self.group)
         e.begin_sweep(mu.cpu().numpy())
         cass, bsq = e.end_sweep()
-        for t in range(T):
-            q = e.delta_export(t)
-            dist.all_reduce(q, op=dist.ReduceOp.SUM, group=self.group)
-            e.delta_import(t, q)
+        if self.world > 1:                              # one shard: nothing to reconcile (exactly the
+            for t in range(T):                          # reference's single-rank chain)
+                q = e.delta_export(t)
+                dist.all_reduce(q, op=dist.ReduceOp.SUM, group=self.group)
+                e.delta_import(t, q)
         cass_t = e.small(np.ascontiguousarray(cass, dtype=np.int32))
         dist.all_reduce(cass_t, op=dist.ReduceOp.SUM, group=self.group)
         bsq_t = e.small(np.ascontiguousarray(bsq, dtype=np.float64))
