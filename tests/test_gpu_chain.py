@@ -163,3 +163,50 @@ def test_marker_sharded_schedule_two_ranks(gpu, tmp_path, name):
         assert np.array_equal(x["eps"], want["eps"])
         assert float(x["sigmae"]) == want["sigmae"][-1]
         assert np.array_equal(x["sigmag"], want["sigmag"][-1])
+
+
+def test_four_traits_run_as_concurrent_chains(gpu):
+    """BASELINE config 4 in miniature: 4 phenotypes at N = 50 000 individuals sweep as four
+    concurrent persistent launches (4 x 49 workgroups fit side by side), sharing the genotype
+    block.  Every trait must equal its own single-trait oracle chain bit for bit; traits 0 and 1
+    get identical phenotypes and must therefore stay identical (the reference's
+    test1.phen / test1_bis.phen property: same seeds for every phenotype, bayes.cpp:796-803)."""
+    case = cases.Case("four", 50_000, 600, 2, 4, 4, 0.0, 300, 31, 2, 30)
+    inp = cases.make_inputs(case)
+    inp["y"][1] = inp["y"][0]
+    inp["isna"][1] = inp["isna"][0]
+    got = cases.run_gpu(case, inp)
+    want = cases.run_oracle(case, inp, canon=True)
+    cases.assert_same_history(got, want, exact=True)
+    assert np.array_equal(got[0]["betas"][-1], got[1]["betas"][-1]) and got[0]["csv"] == got[1]["csv"]
+    assert not np.array_equal(got[0]["betas"][-1], got[2]["betas"][-1])
+
+
+def test_missing_genotypes_and_24_groups_full_width(gpu):
+    """BASELINE config 5's ingredients at full width (N = 500 000): 5 % phenotype NAs, 5 %
+    missing genotypes (general exchange layout), 24 groups.  Checked against the oracle on a
+    block the oracle can afford: two sweeps over 288 markers (12 per group)."""
+    from oracle import orc
+    N, M, G = 500_000, 288, 24
+    rng = np.random.default_rng(9)
+    y = rng.normal(size=N)
+    isna = (rng.random(N) < 0.05).astype(np.uint8)
+    eps, mask4, nonas = orc.phen_prepare(y, isna)
+    ctx = gmrm_amd.Context(N, M)
+    ctx.synth_bed(5, 0.4, 0.05)
+    bed = ctx.download_bed()
+    ctx.upload_trait(0, eps, mask4, nonas)
+    cva = np.tile(np.array([0.0, 0.0001, 0.001, 0.01]), (G, 1))
+    gi = (np.arange(M) % G).astype(np.int32)
+    smp = gmrm_amd.Sampler(ctx, 77, cva, gi)
+    ch = orc.Chain(N, bed, eps, mask4, nonas, gi, cva, 77, canon=True)
+    for it in (1, 2):
+        smp.iterate(it)
+        ch.iterate(it)
+        assert np.array_equal(ctx.comp(0), ch.comp)
+        assert np.array_equal(ctx.betas(0), ch.betas) and np.all(np.isfinite(ch.betas))
+        hy = smp.hyper(0)
+        assert hy.sigmae == ch.sigmae and np.array_equal(hy.sigmag, ch.sigmag)
+    assert np.array_equal(ctx.get_epsilon(0), ch.eps)
+    assert (ctx.betas(0) != 0).sum() > 0
+    smp.close(); ctx.close()
