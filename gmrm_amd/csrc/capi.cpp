@@ -512,6 +512,23 @@ int gmrm_get_acum(gmrm_ctx* c, int t, double* acum) {
     return GMRM_OK;
 }
 
+int gmrm_selftest_math(int device, int op, const double* x, double* y, int n) {
+    if (!x || !y || n < 1 || op < 0 || op > 4 || (op == 3 && n > 65536)) return fail(GMRM_EINVAL, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(GMRM_ENODEV, "no HIP device visible");
+    HIPCHK(hipSetDevice(device));
+    const size_t nout = (size_t)n * (op == 4 ? 2 : 1);
+    double *dx = nullptr, *dy = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dx), (size_t)n * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dy), nout * sizeof(double)));
+    HIPCHK(hipMemcpy(dx, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(launch_selftest(op, dx, dy, n, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(y, dy, nout * sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(dy);
+    return GMRM_OK;
+}
+
 int gmrm_eps_snapshot(gmrm_ctx* c, int t) {
     if (int r = need_trait(c, t, false)) return r;
     HIPCHK(hipSetDevice(c->device));

@@ -14,6 +14,7 @@
 // sums are accumulated on pre-rounded bins (gm_common.h split2), hence exactly and in any
 // order, so the f64 atomics that combine workgroups do not make results run-dependent.
 #include "gm_common.h"
+#include "gm_rng.h"
 #include "gm_internal.h"
 
 namespace gm {
@@ -281,6 +282,44 @@ hipError_t launch_delta_import(double* eps, const double* start, const double* q
     int blocks = (int)((n4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_delta_import, dim3(blocks), dim3(256), 0, st, eps, start, q, n4);
+    return hipGetLastError();
+}
+
+// ---- device arithmetic self-test (gmrm_selftest_math) --------------------------------------
+struct DevMt {                                        // a plain mt19937 in registers/scratch, one thread
+    uint32_t mt[624];
+    int idx;
+    __device__ void seed(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    __device__ uint32_t u32() {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; i++) mt[i] = mt_twist1(mt[i], mt[(i + 1) % 624], mt[(i + 397) % 624]);
+            idx = 0;
+        }
+        return mt_temper(mt[idx++]);
+    }
+};
+__global__ void k_selftest(int op, const double* __restrict__ x, double* __restrict__ y, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (op == 3) {
+        if (i == 0) {
+            DevMt e;
+            e.seed((uint32_t)x[0]);
+            for (int k = 0; k < n; k++) y[k] = norm(e, 0.0, 1.0);
+        }
+        return;
+    }
+    if (i >= n) return;
+    if (op == 0) y[i] = exp_(x[i]);
+    else if (op == 1) y[i] = __builtin_sqrt(x[i]);
+    else if (op == 2) y[i] = 1.0 / x[i];
+    else if (op == 4) { double q1, q2; split2(x[i], q1, q2); y[2 * i] = q1; y[2 * i + 1] = q2; }
+}
+hipError_t launch_selftest(int op, const double* x, double* y, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, st, op, x, y, n);
     return hipGetLastError();
 }
 

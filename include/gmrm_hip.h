@@ -143,6 +143,15 @@ int gmrm_eps_delta_export(gmrm_ctx* ctx, int t, double* dev_q);      /* split2(e
 int gmrm_eps_delta_import(gmrm_ctx* ctx, int t, const double* dev_q);/* eps = start+(q1+q2)  */
 
 /* ------------------------------------------------------------------------------------
+ * Device arithmetic self-test (not on the reference's path): evaluates, on the GPU, the
+ * building blocks whose bit-for-bit agreement with the host the parity claim rests on.
+ *   op 0: y = exp_(x) (the path's exp)      op 1: y = sqrt(x)       op 2: y = 1.0 / x
+ *   op 3: y[i] = i-th normal_distribution(0,1) draw from mt19937(seed = (uint32)x[0]) (n <= 65536)
+ *   op 4: y[2i], y[2i+1] = split2(x[i])  (y holds 2n doubles)
+ * ---------------------------------------------------------------------------------- */
+int gmrm_selftest_math(int device, int op, const double* x, double* y, int n);
+
+/* ------------------------------------------------------------------------------------
  * Host-side sampler: Bayes::process() around the marker loop (src/bayes.cpp:318-371,
  * 556-669) -- prologue draws, shuffle, hyper-parameter updates -- on the RNG spec of
  * DESIGN.md, driving the context above.  One object per context, all T phenotypes.

@@ -164,3 +164,42 @@ def test_error_paths(gpu):
     with pytest.raises(gmrm_amd.GmrmError):
         gmrm_amd.Context(5_000_000, 10)                     # beyond the exact-summation range
     ctx.close()
+
+
+def _selftest(op, x, nout=None):
+    lib = gmrm_amd.load_library()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty(nout if nout else x.size, dtype=np.float64)
+    from gmrm_amd._lib import check
+    check(lib.gmrm_selftest_math(0, op, x.ctypes.data_as(orc.c_double_p), y.ctypes.data_as(orc.c_double_p), x.size))
+    return y
+
+
+def test_device_arithmetic_is_bit_identical_to_host(gpu):
+    """exp_, sqrt, division, split2 and the ziggurat normal on the GPU against the oracle's C
+    (the parity claim is bit-for-bit, so the comparison is on bits, NaNs included)."""
+    L = orc.lib()
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.uniform(-750, 712, 200_000), rng.normal(0, 3, 200_000),
+                         [0.0, -0.0, 709.782712893384, 709.7827128933841, -745.1332191019412, -745.2,
+                          1e-310, np.inf, -np.inf, np.nan, 700.0, -700.0]])
+    got = _selftest(0, xs)
+    want = np.array([L.orc_exp(float(v)) for v in xs])
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    pos = np.abs(np.concatenate([rng.lognormal(0, 20, 100_000), [0.0, 1e-320, 4.0, np.inf]]))
+    assert np.array_equal(_selftest(1, pos).view(np.uint64), np.sqrt(pos).view(np.uint64))
+    den = np.concatenate([rng.lognormal(0, 30, 100_000) * rng.choice([-1.0, 1.0], 100_000), [3.0, 1e-310, 1e308]])
+    assert np.array_equal(_selftest(2, den).view(np.uint64), (1.0 / den).view(np.uint64))
+    e = rng.normal(0, 1.5, 50_000)
+    q = _selftest(4, e, 2 * e.size).reshape(-1, 2)
+    a, b = C.c_double(), C.c_double()
+    for i in range(0, e.size, 97):
+        L.orc_split2(float(e[i]), C.byref(a), C.byref(b))
+        assert q[i, 0] == a.value and q[i, 1] == b.value
+    n = 60_000                                  # enough draws to visit the wedge and tail branches
+    z = _selftest(3, np.full(n, 4242.0))
+    r = orc.OrcRng()
+    L.orc_rng_seed(C.byref(r), 4242)
+    zz = np.array([L.orc_rng_norm(C.byref(r), 0.0, 1.0) for _ in range(n)])
+    assert np.array_equal(z.view(np.uint64), zz.view(np.uint64))
+    assert np.abs(z).max() > 3.5                # the ziggurat tail was exercised
