@@ -417,7 +417,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.N = c->N; a.M = c->M; a.W = c->W; a.Wpad = c->Wpad; a.G = G; a.K = K;
     a.stride = c->stride;
     a.bed = c->bed; a.namask2 = tr.namask2; a.order = tr.order; a.group = c->group;
-    a.mave = tr.mave; a.msig = tr.msig; a.nomiss = tr.nomiss;
+    a.mave = tr.mave; a.msig = tr.msig;
     a.betas_in = tr.betas[tr.cur]; a.betas_out = tr.betas[tr.cur ^ 1];
     a.comp = tr.comp; a.acum = tr.acum; a.eps = tr.eps;
     a.sigmag = tr.tab; a.denom = tr.tab + G; a.logpi = tr.tab + G + (size_t)G * K; a.mhl = tr.tab + G + 2 * (size_t)G * K;

@@ -7,7 +7,7 @@
 // Layout.  The residual never leaves the chip during a sweep: workgroup w / thread t owns
 // R consecutive bytes of every genotype column (4R individuals) and keeps their residual
 // eps_i and its two pre-rounded parts (q1_i, q2_i) in VGPRs.  A marker's dot product is then
-// 4 partial sums per thread (sum a*q1, a*q2, b*q1, b*q2), all exact (gm_common.h), reduced by
+// 4 (or 2) partial sums per thread, all exact (gm_common.h), reduced by
 // wavefront shuffles -> LDS -> one value per workgroup -> cross-workgroup.
 //
 // Schedule.  The chain is sequential (marker j+1 needs the residual after marker j), and a
@@ -18,18 +18,25 @@
 // the batch is then stale.  The residual update is applied and the next batch starts after
 // that marker.  Results are exactly those of the one-marker-at-a-time loop.
 //
+// Pipelining.  While the totals of batch g are in flight, every wavefront already computes and
+// publishes the dots of batch g+1, assuming g ends without a residual update; g+1 is then
+// promoted, otherwise discarded and a fresh batch starts after the stopping marker.  Speculation
+// is switched on only when the recent run length makes P(no update) >~ 1/2.
+//
 // Genotype stream.  The visit order is known for the whole sweep, so each workgroup keeps a
-// 128-position ring of its 256*R-byte column slices in LDS.  Wavefronts 1-2 fetch the slices
-// of upcoming positions (coalesced 2R-byte loads, NA mask applied once) while wavefront 0 is
-// busy with the exchange; phase A and the residual update read the ring, never HBM.
+// 256-position ring of its 256*R-byte column slices in LDS.  Wavefronts 1-2 fetch the slices
+// of upcoming positions (coalesced 2R-byte loads, NA mask applied once) one iteration ahead and
+// park them in the ring just before the next fetch is issued; phase A and the residual update
+// read the ring, never HBM.  Wavefront 3 does the same for the per-marker inputs of the sampling
+// step (marker id, group, previous effect, mave, msig) in a 128-position ring.
 //
 // Exchange per batch (placement-independent, gfx950: private L2 per XCD).  "The data is the
-// flag": every exchanged double travels as two 8-byte granules {tag = batch number + 1,
+// flag": every exchanged double travels as two 8-byte granules {tag = generation + 1,
 // 32 data bits}, each written by ONE sc1 (write-through) store and read by sc1 loads until
-// the tag matches -- no counters, no fences.
-//   1. every workgroup stores its nb*4 partial sums to P[v][wg];
-//   2. workgroup v (v < nb*4) polls row v, reduces it (exact sums: any order), stores the
-//      total Tt[v];
+// the tag matches -- no counters, no fences.  Generation g uses buffer g & 1.
+//   1. every workgroup stores its partial sums (4 per marker, or 2 per marker + 2 per batch in
+//      the no-missing-genotype layout) to P[g&1][v][wg];
+//   2. workgroup v polls row v, reduces it (exact sums: any order), stores the total Tt[g&1][v];
 //   3. wavefront 0 of EVERY workgroup polls the totals and runs the SAME sampling step on the
 //      SAME RNG stream (kept in LDS) -- redundant, hence no broadcast hop.
 // Every spin is bounded (wall-clock timeout -> error word -> all workgroups leave).
@@ -43,10 +50,10 @@ namespace gm {
 constexpr int ring_pos(int R) { return R == 4 ? 128 : 256; }   // ring capacity in order positions
 constexpr int bmax(int R) { return R == 4 ? 32 : 64; }          // markers per batch (two batches + look-ahead fit the ring)
 constexpr int PFN      = 24;                    // positions prefetched per batch per loader thread
-constexpr int L_LUT  = 0;                       // double2[4]   (a,b) per 2-bit code
+constexpr int L_LUT  = 0;                       // (spare, 64 B)
 constexpr int L_VAL  = 64;                      // double[4]    update table of the stopping marker
 constexpr int L_CTL  = 96;                      // int[16]      control words
-constexpr int L_M    = 160;                     // double[4]    a per 2-bit code (+ spare)
+constexpr int L_M    = 160;                     // spare (diagnostic stamps live at +64)
 constexpr int L_RNG0 = 416;                     // uint32[624]  current MT block (untempered)
 constexpr int L_RNG1 = L_RNG0 + 2496;           // uint32[624]  next MT block
 constexpr int L_CASS = L_RNG1 + 2496;           // int[GMAX*KMAX]
@@ -62,7 +69,7 @@ constexpr int L_MIN = 84 * 1024;
 constexpr int lds_total(int R) { return (L_RING + ring_pos(R) * SW_TPB * R) > L_MIN ? (L_RING + ring_pos(R) * SW_TPB * R) : L_MIN; }
 static_assert(lds_total(4) <= 160 * 1024, "LDS budget");
 
-enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_FAST, C_BAD };
+enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD };
 
 size_t sweep_lds_bytes() { return (size_t)lds_total(4); }
 
@@ -465,8 +472,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
     const int W = a.W, K = a.K, G = a.G;
 
-    double2* lut = reinterpret_cast<double2*>(smem + L_LUT);
-    double* luta = reinterpret_cast<double*>(smem + L_M);    // a per 2-bit code (fast layout)
     const double* s_val = reinterpret_cast<const double*>(smem + L_VAL);
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     uint32_t* s_rng0 = reinterpret_cast<uint32_t*>(smem + L_RNG0);
@@ -480,7 +485,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     unsigned long long* Pg = reinterpret_cast<unsigned long long*>(a.P);
     unsigned long long* Ttg = reinterpret_cast<unsigned long long*>(a.Tt);
 
-    if (tid < 4) { lut[tid] = make_double2(code_a(tid), code_b(tid)); luta[tid] = code_a(tid); }
     for (int i = tid; i < 624; i += SW_TPB) s_rng0[i] = a.rng_state[i];
     for (int i = tid; i < G * K; i += SW_TPB) s_cass[i] = 0;
     for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];   // sigmag|denom|logpi|mhl, contiguous
