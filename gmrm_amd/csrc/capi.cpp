@@ -76,6 +76,8 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
     if (c->R < 0) c->R = sweep_pick_R(c->stride, c->num_cu, &c->W);
     if (c->R < 0) { delete c; return fail(GMRM_EINVAL, "N too large for the resident-residual sweep kernel"); }
     c->Wpad = (c->W + 15) / 16 * 16;
+    if (const char* e = std::getenv("GMRM_NB_FACTOR16")) { int v = std::atoi(e); if (v >= 8 && v <= 256) c->nb_factor16 = v; }
+    if (const char* e = std::getenv("GMRM_SPEC_FACTOR16")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) c->spec_factor16 = v; }
 
     hipError_t e = hipSuccess;
     const size_t bedbytes = (size_t)(M > 0 ? M : 1) * c->stride;
@@ -428,6 +430,8 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.cass = tr.cass; a.stats = tr.stats; a.err = tr.err;
     a.P = tr.P; a.Tt = tr.Tt; a.cnt = tr.cnt;
     a.batch_init = c->batch_init;
+    a.nb_factor16 = c->nb_factor16;
+    a.spec_factor16 = c->spec_factor16;
     a.all_nomiss = tr.all_nomiss;
     // Phenotypes that do not fit side by side share stream 0 and run one after another.
     hipStream_t st = c->concurrent ? tr.stream : c->tr[0].stream;

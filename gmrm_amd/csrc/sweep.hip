@@ -318,7 +318,7 @@ struct SampleOut {                 // global outputs, written by workgroup 0 onl
 #endif
 
 template <int K>
-__device__ __noinline__ void sample_batch(int nb, int bmax_, int gran, int G, char* smem, const LaneIn in, double t0, double t1,
+__device__ __noinline__ void sample_batch(int nb, int bmax_, int gran, int nbf16, int G, char* smem, const LaneIn in, double t0, double t1,
                                           double t2, double t3, double sigmae, double inv2sige, double nm1,
                                           const SampleOut out, bool writer) {
     const int lane = threadIdx.x & 63;
@@ -411,7 +411,7 @@ __device__ __noinline__ void sample_batch(int nb, int bmax_, int gran, int G, ch
         const int run = s < nb ? s + 1 : 2 * nb;
         const int ema = (3 * ctl[C_EMA] + 16 * run) / 4;            // fixed point, 1/16 marker
         ctl[C_EMA] = ema;
-        int nxt = ((2 * ema / 16) + gran - 1) / gran * gran;       // whole register groups only
+        int nxt = ((nbf16 * ema / 256) + gran - 1) / gran * gran;  // whole register groups only
         nxt = nxt < gran ? gran : (nxt > bmax_ ? bmax_ : nxt);
         ctl[C_NBNEXT] = nxt;
     }
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             if (nb0 > a.M - pos) nb0 = a.M - pos;
             tb.p0 = pos; tb.nb = nb0; tb.gen = gen_next++;
             do_compute = true;
-        } else if (ctl[C_EMA] >= 24 * cur.nb) {       // speculate only when the recent run length (1/16 units)
+        } else if (ctl[C_EMA] >= a.spec_factor16 * cur.nb) {   // speculate only when the recent run length (1/16 units)
             const int p1 = pos + cur.nb;              // is >= 1.5 batches: P(no residual update) >~ 1/2
             if (p1 < a.M) {
                 int nb1 = ctl[C_NBNEXT];
@@ -795,13 +795,13 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             bad |= !okw;
             if (okw) {
                 switch (K) {
-                    case 2: sample_batch<2>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 3: sample_batch<3>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 4: sample_batch<4>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 5: sample_batch<5>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 6: sample_batch<6>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 7: sample_batch<7>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    default: sample_batch<8>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 2: sample_batch<2>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 3: sample_batch<3>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 4: sample_batch<4>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 5: sample_batch<5>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 6: sample_batch<6>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 7: sample_batch<7>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    default: sample_batch<8>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
                 }
             }
         }
