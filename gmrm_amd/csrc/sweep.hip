@@ -61,8 +61,10 @@ constexpr int L_WSUM = L_CASS + GMAX * KMAX * 4;   // double[4][SW_VMAX]
 constexpr int L_RED  = L_WSUM + 4 * SW_VMAX * 8;   // double[4]
 constexpr int L_TAB  = L_RED + 64;                 // double[GMAX*(1+3*KMAX)] per-group tables
 constexpr int META_POS = 128;                   // per-marker inputs of the sampling step, ring over order positions
-constexpr int L_META = L_TAB + GMAX * (1 + 3 * KMAX) * 8;   // int m[128], int g[128], double beta[128], mave[128], msig[128]
-constexpr int L_RING = L_META + META_POS * 32;              // uint8[ring_pos(R)][SW_TPB*R]
+constexpr int TAB_LDS = 576;                    // group tables up to 576 doubles live in LDS, larger ones stay in HBM/L2
+constexpr int L_META = L_TAB + TAB_LDS * 8;     // int m[128], int g[128], double beta[128], mave[128], msig[128]
+constexpr int L_BLUT = L_META + META_POS * 32;  // double[256][4]: a of the 4 genotypes of a byte (rows swizzled), fast layout
+constexpr int L_RING = L_BLUT + 256 * 32;       // uint8[ring_pos(R)][SW_TPB*R]
 static_assert(L_RING % 16 == 0, "LDS carve");
 // Request > 80 KiB so that exactly one workgroup fits per CU.
 constexpr int L_MIN = 84 * 1024;
@@ -136,6 +138,12 @@ __device__ __forceinline__ double code_b_bits(uint32_t present, int i) {   // pr
     const uint32_t pm = (uint32_t)((int)(present << (31 - 2 * i)) >> 31);
     return mk64(0u, 0x3FF00000u & pm);
 }
+
+// The reference's 256 x 4 dotp_lut_a rows (4 genotypes per byte), staged in LDS for the fast
+// layout: one row = 32 bytes = two ds_read_b128 per genotype byte instead of ~20 VALU decode
+// operations.  A row's bank group is row & 7; rows are placed at e ^ swz(e) so that the skewed
+// byte distribution of real genotypes spreads over all 8 groups.
+__device__ __forceinline__ uint32_t blut_row(uint32_t e) { return e ^ ((e >> 3) & 7u) ^ ((e >> 6) & 3u); }
 
 // 32 per-lane values -> lane l holds value (l >> 1) summed over the 64 lanes.  Each step pairs
 // lanes that agree on every earlier selector bit (masks 32, 16, 15, 7, 3, then 1), so the sums
@@ -318,14 +326,13 @@ struct SampleOut {                 // global outputs, written by workgroup 0 onl
 #endif
 
 template <int K>
-__device__ __noinline__ void sample_batch(int nb, int bmax_, int gran, int nbf16, int G, char* smem, const LaneIn in, double t0, double t1,
+__device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int gran, int nbf16, int G, char* smem, const double* tab, const LaneIn in, double t0, double t1,
                                           double t2, double t3, double sigmae, double inv2sige, double nm1,
                                           const SampleOut out, bool writer) {
     const int lane = threadIdx.x & 63;
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     double* s_val = reinterpret_cast<double*>(smem + L_VAL);
     int* s_cass = reinterpret_cast<int*>(smem + L_CASS);
-    const double* tab = reinterpret_cast<const double*>(smem + L_TAB);
     LdsStream rs{reinterpret_cast<const uint32_t*>(smem + L_RNG0), reinterpret_cast<const uint32_t*>(smem + L_RNG1),
                  ctl[C_CURSOR], &ctl[C_RNGERR]};
 
@@ -417,6 +424,14 @@ __device__ __noinline__ void sample_batch(int nb, int bmax_, int gran, int nbf16
     }
 }
 
+// K = 4 (the reference's example mixtures) is inlined into the kernel; other K share out-of-line copies.
+template <int K>
+__device__ __noinline__ void sample_batch(int nb, int bmax_, int gran, int nbf16, int G, char* smem, const double* tab,
+                                          const LaneIn in, double t0, double t1, double t2, double t3, double sigmae,
+                                          double inv2sige, double nm1, const SampleOut out, bool writer) {
+    sample_batch_body<K>(nb, bmax_, gran, nbf16, G, smem, tab, in, t0, t1, t2, t3, sigmae, inv2sige, nm1, out, writer);
+}
+
 // Wavefront 0: lane j polls the totals of batch position j (tagged granules) until they have
 // arrived.  Returns false on timeout.
 __device__ __forceinline__ bool poll_totals(int nb, bool fast, bool act, const unsigned long long* Ttg, unsigned tag,
@@ -425,23 +440,23 @@ __device__ __forceinline__ bool poll_totals(int nb, bool fast, bool act, const u
     Spin sp;
     sp.start();
     bool bad = false;
-    for (;;) {
-        bool ok = true;
-        if (act) {
-            if (fast) {
-                ok &= get_value(Ttg + 2 * (2 * lane + 0), tag, t0);
-                ok &= get_value(Ttg + 2 * (2 * lane + 1), tag, t1);
-                ok &= get_value(Ttg + 2 * (2 * nb + 0), tag, t2);
-                ok &= get_value(Ttg + 2 * (2 * nb + 1), tag, t3);
-            } else {
-                ok &= get_value(Ttg + 2 * (4 * lane + 0), tag, t0);
-                ok &= get_value(Ttg + 2 * (4 * lane + 1), tag, t1);
-                ok &= get_value(Ttg + 2 * (4 * lane + 2), tag, t2);
-                ok &= get_value(Ttg + 2 * (4 * lane + 3), tag, t3);
+    // Spin on ONE value (two 8-byte loads per lane per round trip); the other three were stored
+    // by neighbouring reducers at about the same time and are normally there on the first look.
+    const unsigned long long* g0 = Ttg + 2 * (fast ? 2 * lane + 0 : 4 * lane + 0);
+    const unsigned long long* g1 = Ttg + 2 * (fast ? 2 * lane + 1 : 4 * lane + 1);
+    const unsigned long long* g2 = Ttg + 2 * (fast ? 2 * nb + 0 : 4 * lane + 2);
+    const unsigned long long* g3 = Ttg + 2 * (fast ? 2 * nb + 1 : 4 * lane + 3);
+    for (int stage = 0; stage < 2; stage++) {
+        for (;;) {
+            bool ok = true;
+            if (act) {
+                if (stage == 0) ok = get_value(g0, tag, t0);
+                else { ok = get_value(g1, tag, t1); ok &= get_value(g2, tag, t2); ok &= get_value(g3, tag, t3); }
             }
+            if (__all(ok)) break;
+            if (sp.expired(abort_word)) { bad = true; break; }
         }
-        if (__all(ok)) break;
-        if (sp.expired(abort_word)) { bad = true; break; }
+        if (__any(bad)) break;
     }
     return !__any(bad);
 }
@@ -480,6 +495,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     double* s_wsum = reinterpret_cast<double*>(smem + L_WSUM);
     double* s_red = reinterpret_cast<double*>(smem + L_RED);
     double* s_tab = reinterpret_cast<double*>(smem + L_TAB);
+    double* blut = reinterpret_cast<double*>(smem + L_BLUT);
+    const bool tab_in_lds = G * (1 + 3 * K) <= TAB_LDS;
+    const double* tabp = tab_in_lds ? s_tab : a.sigmag;   // sigmag|denom|logpi|mhl, contiguous
     char* ring = smem + L_RING;
     unsigned* abort_word = a.cnt + 64;
     unsigned long long* Pg = reinterpret_cast<unsigned long long*>(a.P);
@@ -487,7 +505,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 
     for (int i = tid; i < 624; i += SW_TPB) s_rng0[i] = a.rng_state[i];
     for (int i = tid; i < G * K; i += SW_TPB) s_cass[i] = 0;
-    for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];   // sigmag|denom|logpi|mhl, contiguous
+    if (tab_in_lds)
+        for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];
+    for (int i = tid; i < 1024; i += SW_TPB) blut[blut_row((uint32_t)i >> 2) * 4 + (i & 3)] = code_a(((i >> 2) >> (2 * (i & 3))) & 3);
 #ifdef GM_SWEEP_PROF
     if (tid < 8) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[tid] = 0ull;
 #endif
@@ -661,11 +681,15 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     // unconditional ring read: slots past the batch hold finite junk that nobody consumes
                     const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((p0 + g0 + gm) & (RPOS - 1)) * (SW_TPB * R) + (size_t)tid * R);
                     double sa1 = 0.0, sa2 = 0.0;
-                    const uint32_t nw = ~wd;
 #pragma unroll
-                    for (int i = 0; i < NI; i++) {
-                        const double av = code_a_bits(wd, nw, i);
-                        sa1 = fma_(av, q1[i], sa1); sa2 = fma_(av, q2[i], sa2);
+                    for (int k = 0; k < R; k++) {                  // one table row per genotype byte
+                        const double* row = blut + blut_row((wd >> (8 * k)) & 0xFFu) * 4;
+                        const double2 a01 = *reinterpret_cast<const double2*>(row);
+                        const double2 a23 = *reinterpret_cast<const double2*>(row + 2);
+                        sa1 = fma_(a01.x, q1[4 * k + 0], sa1); sa2 = fma_(a01.x, q2[4 * k + 0], sa2);
+                        sa1 = fma_(a01.y, q1[4 * k + 1], sa1); sa2 = fma_(a01.y, q2[4 * k + 1], sa2);
+                        sa1 = fma_(a23.x, q1[4 * k + 2], sa1); sa2 = fma_(a23.x, q2[4 * k + 2], sa2);
+                        sa1 = fma_(a23.y, q1[4 * k + 3], sa1); sa2 = fma_(a23.y, q2[4 * k + 3], sa2);
                     }
                     acc[gm * 2 + 0] = sa1; acc[gm * 2 + 1] = sa2;
                 }
@@ -795,13 +819,13 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             bad |= !okw;
             if (okw) {
                 switch (K) {
-                    case 2: sample_batch<2>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 3: sample_batch<3>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 4: sample_batch<4>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 5: sample_batch<5>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 6: sample_batch<6>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 7: sample_batch<7>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    default: sample_batch<8>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 2: sample_batch<2>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 3: sample_batch<3>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 4: sample_batch_body<4>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 5: sample_batch<5>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 6: sample_batch<6>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 7: sample_batch<7>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    default: sample_batch<8>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
                 }
             }
         }
