@@ -158,9 +158,11 @@ def main():
         lib.gmrm_ctx_sync(ctx.h)
 
     it = 0
+    warm_ms = []
     for _ in range(a.warmup):
         it += 1
         step(it)
+        warm_ms.append(max(smp.hyper(t).sweep_device_ms for t in range(T)))
     fence()
     t0 = time.perf_counter()
     kern_ms, upd, batches = [], [], []
@@ -208,6 +210,8 @@ def main():
                                          "(separate rocprofv3 --pmc passes of this workload)" if traffic else None,
                          "kernel": "gm::k_sweep (persistent marker loop)",
                          "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "kernel_ms_per_launch": kern_ms, "kernel_ms_warmup_launches": warm_ms,
+                         "kernel_ms_avg_all_launches": (sum(kern_ms) + sum(warm_ms)) / max(1, len(kern_ms) + len(warm_ms)),
                          "algorithmic_bytes_per_launch": alg_bytes},
             "sweep": {"updates_per_sweep": upd, "sync_rounds_per_sweep": batches,
                       "update_fraction": [u / float(M) for u in upd]},

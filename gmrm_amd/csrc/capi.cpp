@@ -75,6 +75,12 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
     c->concurrent = c->R > 0;
     if (c->R < 0) c->R = sweep_pick_R(c->stride, c->num_cu, &c->W);
     if (c->R < 0) { delete c; return fail(GMRM_EINVAL, "N too large for the resident-residual sweep kernel"); }
+    if (const char* e = std::getenv("GMRM_SWEEP_R")) {        // diagnostic override of the bytes-per-thread choice
+        const int r = std::atoi(e);
+        if ((r == 1 || r == 2 || r == 4) && (size_t)r * SW_TPB * 256 >= c->stride && r >= c->R) {
+            c->R = r; c->W = (int)((c->stride + (size_t)SW_TPB * r - 1) / ((size_t)SW_TPB * r));
+        }
+    }
     c->Wpad = (c->W + 15) / 16 * 16;
     if (const char* e = std::getenv("GMRM_NB_FACTOR16")) { int v = std::atoi(e); if (v >= 8 && v <= 256) c->nb_factor16 = v; }
     if (const char* e = std::getenv("GMRM_SPEC_FACTOR16")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) c->spec_factor16 = v; }
@@ -114,6 +120,9 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
         HIPCHK(hipEventCreate(&tr.ev0));
         HIPCHK(hipEventCreate(&tr.ev1));
     }
+    // The zero-fills above run on the null stream and may still be in flight; every later
+    // operation runs on non-blocking streams, which do not wait for the null stream.
+    HIPCHK(hipDeviceSynchronize());
     *out = c;
     return GMRM_OK;
 }
@@ -281,6 +290,7 @@ int gmrm_set_marker_stats(gmrm_ctx* c, int t, const double* mave, const double* 
     HIPCHK(hipMemcpy(c->tr[t].mave, mave, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->tr[t].msig, msig, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(c->tr[t].nomiss, 0, (size_t)(c->M > 0 ? c->M : 1)));   // unknown: general exchange layout
+    HIPCHK(hipDeviceSynchronize());
     c->tr[t].all_nomiss = 0;
     c->tr[t].have_stats = true;
     return GMRM_OK;
@@ -404,10 +414,11 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
             }
         }
     }
-    HIPCHK(hipMemcpyAsync(tr.tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, tr.stream));
-    HIPCHK(hipMemcpyAsync(tr.order, in->order, (size_t)c->M * sizeof(int), hipMemcpyHostToDevice, tr.stream));
-    HIPCHK(hipMemcpyAsync(tr.rng_state, in->rng_state, 624 * sizeof(uint32_t), hipMemcpyHostToDevice, tr.stream));
-    HIPCHK(hipMemcpyAsync(tr.rng_index, &in->rng_index, sizeof(int), hipMemcpyHostToDevice, tr.stream));
+    // blocking copies: the sources (a local table, the caller's sweep_in) need not outlive this call
+    HIPCHK(hipMemcpy(tr.tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(tr.order, in->order, (size_t)c->M * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(tr.rng_state, in->rng_state, 624 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(tr.rng_index, &in->rng_index, sizeof(int), hipMemcpyHostToDevice));
     // every polled word starts at zero in every launch (tags count from 1 inside the launch)
     HIPCHK(hipMemsetAsync(tr.cnt, 0, 96 * sizeof(unsigned), tr.stream));
     HIPCHK(hipMemsetAsync(tr.P, 0, (size_t)4 * SW_VMAX * c->Wpad * sizeof(double), tr.stream));
