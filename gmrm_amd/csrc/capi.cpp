@@ -441,6 +441,13 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.cass = tr.cass; a.stats = tr.stats; a.err = tr.err;
     a.P = tr.P; a.Tt = tr.Tt; a.cnt = tr.cnt;
     a.batch_init = c->batch_init;
+    a.trace = nullptr;
+    if (std::getenv("GMRM_SWEEP_TRACE")) {                  // diagnostic build only
+        if (!tr.trace) HIPCHK(hipMalloc(reinterpret_cast<void**>(&tr.trace), (size_t)256 * 64 * 8 * 8));
+        HIPCHK(hipMemset(tr.trace, 0, (size_t)256 * 64 * 8 * 8));
+        HIPCHK(hipDeviceSynchronize());
+        a.trace = tr.trace;
+    }
     a.nb_factor16 = c->nb_factor16;
     a.spec_factor16 = c->spec_factor16;
     a.all_nomiss = tr.all_nomiss;
@@ -476,6 +483,13 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
         long long st[24];
         HIPCHK(hipMemcpy(st, tr.stats, sizeof(st), hipMemcpyDeviceToHost));
         out->n_updates = st[0]; out->n_batches = st[1];
+        if (const char* path = std::getenv("GMRM_SWEEP_TRACE")) {
+            if (tr.trace) {
+                std::vector<unsigned long long> h((size_t)256 * 64 * 8);
+                HIPCHK(hipMemcpy(h.data(), tr.trace, h.size() * 8, hipMemcpyDeviceToHost));
+                if (FILE* f = std::fopen(path, "ab")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+            }
+        }
         if (std::getenv("GMRM_SWEEP_PROF")) {                  // diagnostic build only (-DGM_SWEEP_PROF)
             static const char* nm[8] = {"promote+reduce", "spec_dots", "pf_issue", "-", "wait_totals", "post_barrier", "update", "sample"};
             for (int w = 0; w < 2; w++) {

@@ -37,6 +37,7 @@ struct Trait {
     double* Tt = nullptr;
     unsigned* cnt = nullptr;
     double* scratch = nullptr;
+    unsigned long long* trace = nullptr;   // diagnostic stamps (GMRM_SWEEP_TRACE)
     hipStream_t stream = nullptr, launch_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };

@@ -44,6 +44,7 @@ struct SweepArgs {
     double* Tt;                    // [SW_VMAX] totals
     unsigned* cnt;                 // [96] arrival counters / abort word, zeroed per launch
     int batch_init;
+    unsigned long long* trace;     // diagnostic build: [W][64][8] wall-clock stamps of rounds 2000..2063, or null
     int nb_factor16;               // next batch = nb_factor16/16 x the run-length EMA (default 16 = 1x; measured best of 1..4x)
     int spec_factor16;             // speculate when EMA >= spec_factor16/16 batches (default 40 = 2.5x)
     int all_nomiss;                // 1: no marker of this block has a missing genotype among the phenotyped individuals

@@ -49,7 +49,7 @@ namespace gm {
 // ---- LDS carve (bytes, all multiples of 16) --------------------------------------------
 constexpr int ring_pos(int R) { return R == 4 ? 128 : 256; }   // ring capacity in order positions
 constexpr int bmax(int R) { return R == 4 ? 32 : 64; }          // markers per batch (two batches + look-ahead fit the ring)
-constexpr int PFN      = 24;                    // positions prefetched per batch per loader thread
+constexpr int PFN      = 24;                    // positions prefetched per batch per loader thread (register-resident; larger spills)
 constexpr int L_LUT  = 0;                       // (spare, 64 B)
 constexpr int L_VAL  = 64;                      // double[4]    update table of the stopping marker
 constexpr int L_CTL  = 96;                      // int[16]      control words
@@ -199,7 +199,10 @@ struct Spin {
     unsigned n;
     __device__ __forceinline__ void start() { t0 = __builtin_amdgcn_s_memrealtime(); n = 0; }
     __device__ __forceinline__ bool expired(unsigned* abort_word) {
-        __builtin_amdgcn_s_sleep(1);
+#ifndef GM_POLL_SLEEP
+#define GM_POLL_SLEEP 1
+#endif
+        __builtin_amdgcn_s_sleep(GM_POLL_SLEEP);
         if ((++n & 63u) != 0u) return false;
         if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull || ld_u32(abort_word) != 0u) {
             st_u32(abort_word, 1u);
@@ -470,6 +473,12 @@ template <> struct Slice<4> { using own_t = uint32_t; using ld_t = unsigned long
 // Diagnostic build only (-DGM_SWEEP_PROF): thread 0 of every workgroup accumulates wall-clock
 // ticks (100 MHz) per phase; workgroups 0 and W/2 write them to stats[4..]/stats[12..].
 #ifdef GM_SWEEP_PROF
+#define TRACE(k) do { if (tid == 0 && a.trace && n_batch >= 2000 && n_batch < 2064) \
+    a.trace[((size_t)wg * 64 + (size_t)(n_batch - 2000)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TRACE(k) do { } while (0)
+#endif
+#ifdef GM_SWEEP_PROF
 #define PROF(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
                                      prof[i] += t_ - tlast; tlast = t_; } } while (0)
 #else
@@ -638,10 +647,17 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (npf > PFN) npf = PFN;
         if (npf < 0) npf = 0;
         if (loader) {
+            // chunks of 8 behind wave-uniform branches: only about npf loads are issued, none waits
+            // on a select (indices are clamped, surplus lanes of the last chunk are dropped at commit)
 #pragma unroll
-            for (int i = 0; i < PFN; i++) {                // unconditional loads (clamped index), consumed at the ring write
-                const int pi = hi + i < a.M ? hi + i : a.M - 1;
-                pf[i] = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[pi] * a.stride + cb);
+            for (int c8 = 0; c8 < PFN; c8 += 8) {
+                if (c8 < npf) {
+#pragma unroll
+                    for (int i = c8; i < c8 + 8; i++) {
+                        const int pi = hi + i < a.M ? hi + i : a.M - 1;
+                        pf[i] = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[pi] * a.stride + cb);
+                    }
+                }
             }
         }
     };
@@ -772,7 +788,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // residual update, speculative next batch); `restart` / `need_reduce` select the case.
     bool restart = true, need_reduce = false, have_next = false;
     while (pos < a.M) {
-        if (need_reduce) { bad = reduce_role(cur); need_reduce = false; }
+        TRACE(restart ? 0 : 7);
+        if (need_reduce) { bad = reduce_role(cur); need_reduce = false; TRACE(2); }
         PROF(0);   // reduce role
         bool do_compute = false;
         if (restart) {
@@ -794,6 +811,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             ensure_meta(pos, tb.p0 + tb.nb);
             compute_publish(tb, tl);
         }
+        if (restart) TRACE(1);
         PROF(1);   // dots + publish (restart: on the critical path; speculative: overlaps the exchange)
         if (restart) {
             cur = tb; li_cur = tl;
@@ -815,6 +833,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
             double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
             const bool okw = poll_totals(cur.nb, cur.fast, lane < cur.nb, Tb, cur.gen + 1u, t0, t1, t2, t3, abort_word);
+            TRACE(3);
             PROF(4);   // wait for the totals
             bad |= !okw;
             if (okw) {
@@ -833,6 +852,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (bad) ctl[C_BAD] = 1;
         lds_barrier();                                // no vmcnt drain: prefetches stay in flight
         if (ctl[C_BAD] || ctl[C_RNGERR]) { ok = false; break; }
+        TRACE(5);
         PROF(5);   // barrier after sampling
 
         // ---- phase C: residual update of the stopping marker (its slice is in the ring) ----
@@ -852,6 +872,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
         pos += n_done;
         n_batch++;
+        TRACE(6);
         PROF(6);   // residual update + ring write
         if (ctl[C_CURSOR] >= 624) block_advance(s_rng0, s_rng1, ctl, true);
         if (upd || n_done < cur.nb || !have_next) {   // the speculative batch (if any) is stale: restart
