@@ -491,7 +491,7 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
             }
         }
         if (std::getenv("GMRM_SWEEP_PROF")) {                  // diagnostic build only (-DGM_SWEEP_PROF)
-            static const char* nm[8] = {"promote+reduce", "spec_dots", "pf_issue", "-", "wait_totals", "post_barrier", "update", "sample"};
+            static const char* nm[8] = {"promote+reduce", "dots", "pf_issue", "pf_commit", "wait_totals", "post_barrier", "update", "sample"};
             for (int w = 0; w < 2; w++) {
                 std::fprintf(stderr, "[sweep prof wg %s] batches %lld (discarded %lld):", w ? "W/2" : "0", st[1], st[3]);
                 for (int i = 0; i < 8; i++)

@@ -4,11 +4,22 @@
 //   Gibbs step                  src/bayes.cpp:396-492      -> sample_batch (wavefront 0)
 //   Phenotype::update_epsilon   src/phenotype.cpp:326-393  -> phase C (all workgroups)
 //
-// Layout.  The residual never leaves the chip during a sweep: workgroup w / thread t owns
-// R consecutive bytes of every genotype column (4R individuals) and keeps their residual
-// eps_i and its two pre-rounded parts (q1_i, q2_i) in VGPRs.  A marker's dot product is then
-// 4 (or 2) partial sums per thread, all exact (gm_common.h), reduced by
-// wavefront shuffles -> LDS -> one value per workgroup -> cross-workgroup.
+// Layout.  The residual never leaves the chip during a sweep: workgroup w owns SB = 256*R
+// consecutive bytes of every genotype column (4*SB individuals); thread t keeps the residual
+// eps_i of its 4R individuals in VGPRs (for the update).  For the dot products the two exact parts
+// of every residual (gm_common.h: q1 on the 2^-22 grid, q2 on the 2^-53 grid, both < 2^31 grid
+// units) are ALSO kept in LDS as 31-bit integers cut into four signed base-256 digits and
+// transposed into "planes": one 32-byte record per genotype byte = 4 individuals x 8 digit planes.
+//
+// Phase A is marker-per-lane: lane l owns marker l of the batch and walks that marker's slice
+// bytes; one 4-byte LUT read turns a genotype byte into the four 8-bit a-values (the reference's
+// dotp_lut_a row, src/dotp_lut.hpp, as int8), and eight v_dot4c_i32_i8 accumulate them against the
+// eight digit planes.  The planes are the same for all markers: each lane of a 16-lane row loads
+// the record of ONE byte of the current 16-byte chunk and the dot4 reads it through DPP
+// row_newbcast -- no LDS broadcast traffic, no cross-lane reduction, no f64 in the loop.  Integer
+// sums are exact, so the results are bit-identical to the f64 formulation (oracle "canon" mode).
+// The batch's threads split the slice nsub = 256/nbp ways (nbp = batch size rounded up to a power
+// of two); the nsub partial sums per marker meet in LDS through 64-bit integer atomics.
 //
 // Schedule.  The chain is sequential (marker j+1 needs the residual after marker j), and a
 // grid-wide exchange costs microseconds on an 8-XCD part, so markers are processed in
@@ -23,12 +34,13 @@
 // promoted, otherwise discarded and a fresh batch starts after the stopping marker.  Speculation
 // is switched on only when the recent run length makes P(no update) >~ 1/2.
 //
-// Genotype stream.  The visit order is known for the whole sweep, so each workgroup keeps a
-// 256-position ring of its 256*R-byte column slices in LDS.  Wavefronts 1-2 fetch the slices
-// of upcoming positions (coalesced 2R-byte loads, NA mask applied once) one iteration ahead and
-// park them in the ring just before the next fetch is issued; phase A and the residual update
-// read the ring, never HBM.  Wavefront 3 does the same for the per-marker inputs of the sampling
-// step (marker id, group, previous effect, mave, msig) in a 128-position ring.
+// Genotype stream.  The visit order is known for the whole sweep, so each workgroup keeps a ring
+// of RPOS column slices in LDS (16-byte chunks XOR-swizzled by position so that 64 lanes reading
+// 64 different slices hit different banks).  Wavefronts 1-2 fetch the slices of upcoming positions
+// as coalesced 16-byte loads one round ahead, hold them in registers while the round runs and park
+// them in the ring once the sampled batch has released its slots (NA mask applied once, there).
+// Wavefront 3 does the same for the per-marker inputs of the sampling step (marker id, group,
+// previous effect, mave, msig).
 //
 // Exchange per batch (placement-independent, gfx950: private L2 per XCD).  "The data is the
 // flag": every exchanged double travels as two 8-byte granules {tag = generation + 1,
@@ -46,34 +58,50 @@
 
 namespace gm {
 
+// ---- geometry per R (bytes of a column per thread) -------------------------------------------
+template <int R> struct Geo {
+    static constexpr int SB = SW_TPB * R;                 // slice bytes per workgroup (= genotype bytes = plane records)
+    static constexpr int CPP = SB / 16;                   // 16-byte chunks per position
+    static constexpr int RPOS = R == 4 ? 96 : 240;        // ring capacity in order positions
+    static constexpr int BMAXF = RPOS / 2;                // markers per batch, no-missing layout (2 values/marker)
+    static constexpr int BMAXG = RPOS / 2 < 64 ? RPOS / 2 : 64;   // general layout (4 values/marker <= SW_VMAX)
+    static constexpr int NL = 192;                        // loader threads (wavefronts 1-3)
+    static constexpr int PPI = NL / CPP;                  // positions covered by one load instruction
+    static constexpr int PFG = 4;                         // loads per wave-uniform branch
+    static constexpr int PFN = ((BMAXF + PPI - 1) / PPI + PFG - 1) / PFG * PFG;   // loads per loader thread per round
+    static_assert(NL % CPP == 0 && PPI >= 1, "loader mapping");
+    static_assert(2 * BMAXF + 2 <= SW_VMAX && 4 * BMAXG <= SW_VMAX, "exchange rows");
+};
+
 // ---- LDS carve (bytes, all multiples of 16) --------------------------------------------
-constexpr int ring_pos(int R) { return R == 4 ? 128 : 256; }   // ring capacity in order positions
-constexpr int bmax(int R) { return R == 4 ? 32 : 64; }          // markers per batch (two batches + look-ahead fit the ring)
-constexpr int PFN      = 24;                    // positions prefetched per batch per loader thread (register-resident; larger spills)
-constexpr int L_LUT  = 0;                       // (spare, 64 B)
 constexpr int L_VAL  = 64;                      // double[4]    update table of the stopping marker
 constexpr int L_CTL  = 96;                      // int[16]      control words
-constexpr int L_M    = 160;                     // spare (diagnostic stamps live at +64)
+constexpr int L_RED  = 160;                     // double[4]    reducer scratch
+constexpr int L_WSQ  = 192;                     // double[4][2] per-wavefront sum of q1 / q2
+constexpr int L_M    = 256;                     // diagnostic stamps (64 B at +64)
 constexpr int L_RNG0 = 416;                     // uint32[624]  current MT block (untempered)
 constexpr int L_RNG1 = L_RNG0 + 2496;           // uint32[624]  next MT block
 constexpr int L_CASS = L_RNG1 + 2496;           // int[GMAX*KMAX]
-constexpr int L_WSUM = L_CASS + GMAX * KMAX * 4;   // double[4][SW_VMAX]
-constexpr int L_RED  = L_WSUM + 4 * SW_VMAX * 8;   // double[4]
-constexpr int L_TAB  = L_RED + 64;                 // double[GMAX*(1+3*KMAX)] per-group tables
-constexpr int META_POS = 128;                   // per-marker inputs of the sampling step, ring over order positions
-constexpr int TAB_LDS = 576;                    // group tables up to 576 doubles live in LDS, larger ones stay in HBM/L2
-constexpr int L_META = L_TAB + TAB_LDS * 8;     // int m[128], int g[128], double beta[128], mave[128], msig[128]
-constexpr int L_BLUT = L_META + META_POS * 32;  // double[256][4]: a of the 4 genotypes of a byte (rows swizzled), fast layout
-constexpr int L_RING = L_BLUT + 256 * 32;       // uint8[ring_pos(R)][SW_TPB*R]
-static_assert(L_RING % 16 == 0, "LDS carve");
+constexpr int L_SUM  = L_CASS + GMAX * KMAX * 4;   // int64[SW_VMAX]  per-batch integer sums of this workgroup
+constexpr int TAB_LDS = 320;                    // group tables up to 320 doubles live in LDS, larger ones stay in HBM/L2
+constexpr int L_TAB  = L_SUM + SW_VMAX * 8;     // double[TAB_LDS] per-group tables
+constexpr int META_POS = 256;                   // per-marker inputs of the sampling step, ring over order positions
+constexpr int L_META = L_TAB + TAB_LDS * 8;     // int m[256], int g[256], double beta[256], mave[256], msig[256]
+constexpr int L_LUTA = L_META + META_POS * 32;  // uint32[256]: a of the 4 genotypes of a byte as 4 x int8
+constexpr int L_LUTB = L_LUTA + 1024;           // uint32[256]: b likewise
+constexpr int L_PLN  = L_LUTB + 1024;           // uint32[SB][8]: digit planes of the residual
+template <int R> constexpr int l_ring() { return L_PLN + Geo<R>::SB * 32; }
+static_assert(L_PLN % 16 == 0, "LDS carve");
 // Request > 80 KiB so that exactly one workgroup fits per CU.
 constexpr int L_MIN = 84 * 1024;
-constexpr int lds_total(int R) { return (L_RING + ring_pos(R) * SW_TPB * R) > L_MIN ? (L_RING + ring_pos(R) * SW_TPB * R) : L_MIN; }
-static_assert(lds_total(4) <= 160 * 1024, "LDS budget");
+template <int R> constexpr int lds_total() {
+    return (l_ring<R>() + Geo<R>::RPOS * Geo<R>::SB) > L_MIN ? (l_ring<R>() + Geo<R>::RPOS * Geo<R>::SB) : L_MIN;
+}
+static_assert(lds_total<1>() <= 160 * 1024 && lds_total<2>() <= 160 * 1024 && lds_total<4>() <= 160 * 1024, "LDS budget");
 
 enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD };
 
-size_t sweep_lds_bytes() { return (size_t)lds_total(4); }
+size_t sweep_lds_bytes() { return (size_t)lds_total<2>(); }   // the largest of the three carves
 
 // Every word another workgroup reads or writes inside the launch is accessed through a
 // GLOBAL (address space 1) agent-scope atomic: global_load/store ... sc1, never flat_.
@@ -109,12 +137,6 @@ __device__ __forceinline__ void swap32(double& a, double& b) {
     const auto h = __builtin_amdgcn_permlane32_swap(hi32(a), hi32(b), false, false);
     a = mk64(l[0], h[0]); b = mk64(l[1], h[1]);
 }
-// rows of 16 lanes: a' = [a.r0, b.r0, a.r2, b.r2], b' = [a.r1, b.r1, a.r3, b.r3]
-__device__ __forceinline__ void swap16(double& a, double& b) {
-    const auto l = __builtin_amdgcn_permlane16_swap(lo32(a), lo32(b), false, false);
-    const auto h = __builtin_amdgcn_permlane16_swap(hi32(a), hi32(b), false, false);
-    a = mk64(l[0], h[0]); b = mk64(l[1], h[1]);
-}
 template <int CTRL> __device__ __forceinline__ double dpp64(double x) {
     const int l = __builtin_amdgcn_update_dpp(0, (int)lo32(x), CTRL, 0xf, 0xf, false);
     const int h = __builtin_amdgcn_update_dpp(0, (int)hi32(x), CTRL, 0xf, 0xf, false);
@@ -125,57 +147,6 @@ constexpr int DPP_ROW_HALF_MIRROR = 0x141;   // lane ^ 7
 constexpr int DPP_QUAD_3210 = 0x1B;          // lane ^ 3
 constexpr int DPP_QUAD_1032 = 0xB1;          // lane ^ 1
 
-// Genotype decode without a table read (an LDS read per individual costs ~70 exposed cycles at
-// one wavefront per SIMD): a = {2,0,1,0}[c], b = {1,0,1,1}[c] as IEEE doubles built from the code
-// bits -- high word 0x40000000 - (h << 20) masked by !l for a, 0x3FF00000 masked by !(l & !h) for b.
-// The values are those of the reference's dotp_lut_a / dotp_lut_b rows (src/dotp_lut.hpp).
-__device__ __forceinline__ double code_a_bits(uint32_t w, uint32_t nw, int i) {
-    const uint32_t h = (w >> (2 * i + 1)) & 1u;
-    const uint32_t nl = (uint32_t)((int)(nw << (31 - 2 * i)) >> 31);        // all ones when the low bit is 0
-    return mk64(0u, (0x40000000u - (h << 20)) & nl);
-}
-__device__ __forceinline__ double code_b_bits(uint32_t present, int i) {   // present: bit 2i set unless code == 01
-    const uint32_t pm = (uint32_t)((int)(present << (31 - 2 * i)) >> 31);
-    return mk64(0u, 0x3FF00000u & pm);
-}
-
-// The reference's 256 x 4 dotp_lut_a rows (4 genotypes per byte), staged in LDS for the fast
-// layout: one row = 32 bytes = two ds_read_b128 per genotype byte instead of ~20 VALU decode
-// operations.  A row's bank group is row & 7; rows are placed at e ^ swz(e) so that the skewed
-// byte distribution of real genotypes spreads over all 8 groups.
-__device__ __forceinline__ uint32_t blut_row(uint32_t e) { return e ^ ((e >> 3) & 7u) ^ ((e >> 6) & 3u); }
-
-// 32 per-lane values -> lane l holds value (l >> 1) summed over the 64 lanes.  Each step pairs
-// lanes that agree on every earlier selector bit (masks 32, 16, 15, 7, 3, then 1), so the sums
-// telescope exactly like an xor butterfly; the sums are exact, so the pairing order is free.
-__device__ __forceinline__ double reduce32(double (&acc)[32], int lane) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) { swap32(acc[i], acc[i + 16]); acc[i] = acc[i] + acc[i + 16]; }
-#pragma unroll
-    for (int i = 0; i < 8; i++) { swap16(acc[i], acc[i + 8]); acc[i] = acc[i] + acc[i + 8]; }
-    {
-        const bool up = (lane & 8) != 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const double send = up ? acc[i] : acc[i + 4], keep = up ? acc[i + 4] : acc[i];
-            acc[i] = keep + dpp64<DPP_ROW_MIRROR>(send);
-        }
-    }
-    {
-        const bool up = (lane & 4) != 0;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const double send = up ? acc[i] : acc[i + 2], keep = up ? acc[i + 2] : acc[i];
-            acc[i] = keep + dpp64<DPP_ROW_HALF_MIRROR>(send);
-        }
-    }
-    {
-        const bool up = (lane & 2) != 0;
-        const double send = up ? acc[0] : acc[1], keep = up ? acc[1] : acc[0];
-        acc[0] = keep + dpp64<DPP_QUAD_3210>(send);
-    }
-    return acc[0] + dpp64<DPP_QUAD_1032>(acc[0]);
-}
 // two per-lane values -> lanes 0-31 hold sum(a), lanes 32-63 hold sum(b)
 __device__ __forceinline__ double reduce2(double a, double b) {
     swap32(a, b);
@@ -302,8 +273,9 @@ __device__ __forceinline__ void decide_rest(double prob, double acum0, const dou
     acum_v = acum;
 }
 
-// What lane j of the sampling wavefront needs about batch position j; fetched at batch
-// start (these loads do not depend on the dots) so they are in registers when the totals land.
+// What the sampling wavefront needs about a batch position; lane j holds positions j and j + 64.
+// Fetched at batch start (these loads do not depend on the dots) so they are in registers when
+// the totals land.
 struct LaneIn {
     int m, g;
     double beta_old, mave, msig;
@@ -317,10 +289,11 @@ struct SampleOut {                 // global outputs, written by workgroup 0 onl
     double* betas_out;
     int* comp;
 };
+struct Totals { double t0, t1, t2, t3; };
 
 // The Gibbs step for a whole batch, run by wavefront 0 of EVERY workgroup on identical
-// inputs.  Lane j handles batch position j; the walk stops at the first lane whose effect
-// may change.  Returns false on a poll timeout.
+// inputs.  Lane j handles batch positions j and 64 + j (two passes); the walk stops at the first
+// marker whose effect may change.
 #ifdef GM_SWEEP_PROF
 #define SSTAMP(i) do { if (lane == 0) { unsigned long long* sp_ = reinterpret_cast<unsigned long long*>(smem + L_M + 64); \
                        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); sp_[i] += t_ - sp_[7]; sp_[7] = t_; } } while (0)
@@ -329,9 +302,9 @@ struct SampleOut {                 // global outputs, written by workgroup 0 onl
 #endif
 
 template <int K>
-__device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int gran, int nbf16, int G, char* smem, const double* tab, const LaneIn in, double t0, double t1,
-                                          double t2, double t3, double sigmae, double inv2sige, double nm1,
-                                          const SampleOut out, bool writer) {
+__device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, int G, char* smem, const double* tab,
+                                                  const LaneIn (&lin)[2], const Totals (&tot)[2], double sigmae,
+                                                  double inv2sige, double nm1, const SampleOut out, bool writer) {
     const int lane = threadIdx.x & 63;
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     double* s_val = reinterpret_cast<double*>(smem + L_VAL);
@@ -342,123 +315,145 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int gran, i
 #ifdef GM_SWEEP_PROF
     if (lane == 0) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[7] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const bool act = lane < nb;
-    const int m = in.m, g = in.g;
-    const double beta_old = in.beta_old;
-    const bool sig0 = act && (tab[g] == 0.0);                   // bayes.cpp:396-400
-    const bool use = act && !sig0;
-    const unsigned long long use_mask = __ballot(use);
-    const int prefix = __popcll(use_mask & ((1ull << lane) - 1ull));
-    const int cursor0 = rs.cursor;
-    const double prob = unif_from_word(rs.peek(cursor0 + prefix));   // bayes.cpp:435
+    int cursor = rs.cursor;                      // wave-uniform: RNG words consumed so far
+    int run = 2 * nb;                            // markers walked, for the batch-size estimate
+    bool stopped = false;
+#pragma unroll 1
+    for (int part = 0; part < 2; part++) {                           // one copy of the code (instruction cache)
+        const int base = 64 * part;
+        if (stopped || base >= nb) break;
+        const int nbp = nb - base < 64 ? nb - base : 64;
+        const LaneIn in = part == 0 ? lin[0] : lin[1];
+        const Totals tt = part == 0 ? tot[0] : tot[1];
+        const bool act = lane < nbp;
+        const int m = in.m, g = in.g;
+        const double beta_old = in.beta_old;
+        const bool sig0 = act && (tab[g] == 0.0);                   // bayes.cpp:396-400
+        const bool use = act && !sig0;
+        const unsigned long long use_mask = __ballot(use);
+        const int prefix = __popcll(use_mask & ((1ull << lane) - 1ull));
+        const int cursor0 = cursor;
+        const double prob = unif_from_word(rs.peek(cursor0 + prefix));   // bayes.cpp:435
 
-    SSTAMP(0);   // inputs, RNG peek
-    int kc = 0;
-    double acum_v = 1.0, muk_c = 0.0, denom_c = 1.0;
-    double muk[K], logl[K];
+        SSTAMP(0);   // inputs, RNG peek
+        int kc = 0;
+        double acum_v = 1.0, muk_c = 0.0, denom_c = 1.0;
+        double muk[K], logl[K];
 #pragma unroll
-    for (int i = 0; i < K; i++) { muk[i] = 0.0; logl[i] = 0.0; }
-    const double* denom_g = tab + G + g * K;
-    if (use) {
-        const double dpa = t0 + t1, dpb = t2 + t3;
-        double num = in.msig * (dpa - in.mave * dpb);               // bayes.cpp:765
-        num += beta_old * nm1;                                       // bayes.cpp:421
-        acum_v = decide0<K>(num, denom_g, tab + G + G * K + g * K, tab + G + 2 * G * K + g * K, inv2sige, muk, logl);
-    }
-    SSTAMP(1);   // decide0
-    // a lane whose draw exceeds acum0 ends in a component > 0 (bayes.cpp:451,476): it stops the walk
-    const bool stop = use && (!(prob <= acum_v) || beta_old != 0.0);
-    const unsigned long long stop_mask = __ballot(stop);
-    const int s = stop_mask ? (__ffsll((long long)stop_mask) - 1) : nb;
-    const int n_done = s < nb ? s + 1 : nb;
-    if (s < nb && lane == s && !(prob <= acum_v)) {                 // the component search, one lane
-        decide_rest<K>(prob, acum_v, logl, kc, acum_v);
+        for (int i = 0; i < K; i++) { muk[i] = 0.0; logl[i] = 0.0; }
+        const double* denom_g = tab + G + g * K;
+        if (use) {
+            const double dpa = tt.t0 + tt.t1, dpb = tt.t2 + tt.t3;
+            double num = in.msig * (dpa - in.mave * dpb);               // bayes.cpp:765
+            num += beta_old * nm1;                                       // bayes.cpp:421
+            acum_v = decide0<K>(num, denom_g, tab + G + G * K + g * K, tab + G + 2 * G * K + g * K, inv2sige, muk, logl);
+        }
+        SSTAMP(1);   // decide0
+        // a lane whose draw exceeds acum0 ends in a component > 0 (bayes.cpp:451,476): it stops the walk
+        const bool stop = use && (!(prob <= acum_v) || beta_old != 0.0);
+        const unsigned long long stop_mask = __ballot(stop);
+        const int s = stop_mask ? (__ffsll((long long)stop_mask) - 1) : nbp;
+        const int n_done = s < nbp ? s + 1 : nbp;
+        if (s < nbp && lane == s && !(prob <= acum_v)) {                // the component search, one lane
+            decide_rest<K>(prob, acum_v, logl, kc, acum_v);
 #pragma unroll
-        for (int i = 1; i < K; i++)
-            if (i == kc) { muk_c = muk[i]; denom_c = denom_g[i]; }
-    }
+            for (int i = 1; i < K; i++)
+                if (i == kc) { muk_c = muk[i]; denom_c = denom_g[i]; }
+        }
 
-    SSTAMP(2);   // component search
-    if (act && lane < n_done && lane != s) {
-        if (sig0) {
-            if (writer) { out.acum[m] = 1.0; out.betas_out[m] = 0.0; }
-        } else if (writer) {                                         // component 0, effect stays 0
-            out.acum[m] = acum_v; out.betas_out[m] = 0.0; out.comp[m] = 0;
-            atomicAdd(&s_cass[g * K + 0], 1);
+        SSTAMP(2);   // component search
+        if (act && lane < n_done && lane != s) {
+            if (sig0) {
+                if (writer) { out.acum[m] = 1.0; out.betas_out[m] = 0.0; }
+            } else if (writer) {                                         // component 0, effect stays 0
+                out.acum[m] = acum_v; out.betas_out[m] = 0.0; out.comp[m] = 0;
+                atomicAdd(&s_cass[g * K + 0], 1);
+            }
         }
+        if (s < nbp && lane == s) {                                      // the stopping marker
+            rs.cursor = cursor0 + prefix + 1;
+            double beta_new = 0.0;
+            if (kc > 0) beta_new = norm(rs, muk_c, sigmae / denom_c);    // bayes.cpp:455
+            const double dbeta = beta_old - beta_new;                    // bayes.cpp:479
+            int upd = 0;
+            if (fabs(dbeta) > 0.0) {                                     // bayes.cpp:483, phenotype.cpp:328-329,388
+                upd = 1;
+                const double bs_ = dbeta * in.msig;
+                const double mdb = -in.mave;
+                s_val[0] = (mdb * 1.0 + 2.0) * bs_;
+                s_val[1] = (mdb * 0.0 + 0.0) * bs_;
+                s_val[2] = (mdb * 1.0 + 1.0) * bs_;
+                s_val[3] = (mdb * 1.0 + 0.0) * bs_;
+            }
+            if (writer) {
+                out.acum[m] = acum_v; out.betas_out[m] = beta_new; out.comp[m] = kc;
+                atomicAdd(&s_cass[g * K + kc], 1);
+            }
+            ctl[C_UPD] = upd;
+            ctl[C_SUPD] = base + s;
+            ctl[C_CURSOR] = rs.cursor;
+            ctl[C_NDONE] = base + n_done;
+        }
+        SSTAMP(3);   // commit + stop lane
+        if (s < nbp) { stopped = true; run = base + s + 1; }
+        else cursor = cursor0 + __popcll(use_mask);
     }
-    if (s < nb && lane == s) {                                       // the stopping marker
-        rs.cursor = cursor0 + prefix + 1;
-        double beta_new = 0.0;
-        if (kc > 0) beta_new = norm(rs, muk_c, sigmae / denom_c);    // bayes.cpp:455
-        const double dbeta = beta_old - beta_new;                    // bayes.cpp:479
-        int upd = 0;
-        if (fabs(dbeta) > 0.0) {                                     // bayes.cpp:483, phenotype.cpp:328-329,388
-            upd = 1;
-            const double bs_ = dbeta * in.msig;
-            const double mdb = -in.mave;
-            s_val[0] = (mdb * 1.0 + 2.0) * bs_;
-            s_val[1] = (mdb * 0.0 + 0.0) * bs_;
-            s_val[2] = (mdb * 1.0 + 1.0) * bs_;
-            s_val[3] = (mdb * 1.0 + 0.0) * bs_;
-        }
-        if (writer) {
-            out.acum[m] = acum_v; out.betas_out[m] = beta_new; out.comp[m] = kc;
-            atomicAdd(&s_cass[g * K + kc], 1);
-        }
-        ctl[C_UPD] = upd;
-        ctl[C_SUPD] = s;
-        ctl[C_CURSOR] = rs.cursor;
-        ctl[C_NDONE] = n_done;
-    }
-    SSTAMP(3);   // commit + stop lane
-    if (s >= nb && lane == 0) {
+    if (!stopped && lane == 0) {
         ctl[C_UPD] = 0;
-        ctl[C_CURSOR] = cursor0 + __popcll(use_mask);
-        ctl[C_NDONE] = n_done;
+        ctl[C_CURSOR] = cursor;
+        ctl[C_NDONE] = nb;
     }
-    if (lane == 0) {                                                 // next batch size: ~2x the recent run length
-        const int run = s < nb ? s + 1 : 2 * nb;
+    if (lane == 0) {                                                 // next batch size from the recent run length
         const int ema = (3 * ctl[C_EMA] + 16 * run) / 4;            // fixed point, 1/16 marker
         ctl[C_EMA] = ema;
-        int nxt = ((nbf16 * ema / 256) + gran - 1) / gran * gran;  // whole register groups only
-        nxt = nxt < gran ? gran : (nxt > bmax_ ? bmax_ : nxt);
-        ctl[C_NBNEXT] = nxt;
+        const int want = nbf16 * ema / 256;
+        int nxt = 16;                                                // a power of two >= want: lanes are free up to it
+        while (nxt < want && nxt < bmax_) nxt *= 2;
+        ctl[C_NBNEXT] = nxt > bmax_ ? bmax_ : nxt;
     }
 }
 
 // K = 4 (the reference's example mixtures) is inlined into the kernel; other K share out-of-line copies.
 template <int K>
-__device__ __noinline__ void sample_batch(int nb, int bmax_, int gran, int nbf16, int G, char* smem, const double* tab,
-                                          const LaneIn in, double t0, double t1, double t2, double t3, double sigmae,
+__device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, char* smem, const double* tab,
+                                          const LaneIn (&lin)[2], const Totals (&tot)[2], double sigmae,
                                           double inv2sige, double nm1, const SampleOut out, bool writer) {
-    sample_batch_body<K>(nb, bmax_, gran, nbf16, G, smem, tab, in, t0, t1, t2, t3, sigmae, inv2sige, nm1, out, writer);
+    sample_batch_body<K>(nb, bmax_, nbf16, G, smem, tab, lin, tot, sigmae, inv2sige, nm1, out, writer);
 }
 
-// Wavefront 0: lane j polls the totals of batch position j (tagged granules) until they have
-// arrived.  Returns false on timeout.
-__device__ __forceinline__ bool poll_totals(int nb, bool fast, bool act, const unsigned long long* Ttg, unsigned tag,
-                                            double& t0, double& t1, double& t2, double& t3, unsigned* abort_word) {
+// Wavefront 0: lane j polls the totals of batch positions j and 64 + j (tagged granules) until
+// they have arrived.  Returns false on timeout.
+__device__ __forceinline__ bool poll_totals(int nb, bool fast, const unsigned long long* Ttg, unsigned tag,
+                                            Totals (&tot)[2], unsigned* abort_word) {
     const int lane = threadIdx.x & 63;
     Spin sp;
     sp.start();
     bool bad = false;
-    // Spin on ONE value (two 8-byte loads per lane per round trip); the other three were stored
-    // by neighbouring reducers at about the same time and are normally there on the first look.
-    const unsigned long long* g0 = Ttg + 2 * (fast ? 2 * lane + 0 : 4 * lane + 0);
-    const unsigned long long* g1 = Ttg + 2 * (fast ? 2 * lane + 1 : 4 * lane + 1);
-    const unsigned long long* g2 = Ttg + 2 * (fast ? 2 * nb + 0 : 4 * lane + 2);
-    const unsigned long long* g3 = Ttg + 2 * (fast ? 2 * nb + 1 : 4 * lane + 3);
-    for (int stage = 0; stage < 2; stage++) {
-        for (;;) {
-            bool ok = true;
-            if (act) {
-                if (stage == 0) ok = get_value(g0, tag, t0);
-                else { ok = get_value(g1, tag, t1); ok &= get_value(g2, tag, t2); ok &= get_value(g3, tag, t3); }
+#pragma unroll 1
+    for (int part = 0; part < 2; part++) {
+        const int j = lane + 64 * part;
+        if (64 * part >= nb) break;
+        const bool act = j < nb;
+        // Spin on ONE value (two 8-byte loads per lane per round trip); the other three were stored
+        // by neighbouring reducers at about the same time and are normally there on the first look.
+        const unsigned long long* g0 = Ttg + 2 * (fast ? 2 * j + 0 : 4 * j + 0);
+        const unsigned long long* g1 = Ttg + 2 * (fast ? 2 * j + 1 : 4 * j + 1);
+        const unsigned long long* g2 = Ttg + 2 * (fast ? 2 * nb + 0 : 4 * j + 2);
+        const unsigned long long* g3 = Ttg + 2 * (fast ? 2 * nb + 1 : 4 * j + 3);
+        Totals t{0.0, 0.0, 0.0, 0.0};
+        for (int stage = 0; stage < 2; stage++) {
+            for (;;) {
+                bool ok = true;
+                if (act) {
+                    if (stage == 0) ok = get_value(g0, tag, t.t0);
+                    else { ok = get_value(g1, tag, t.t1); ok &= get_value(g2, tag, t.t2); ok &= get_value(g3, tag, t.t3); }
+                }
+                if (__all(ok)) break;
+                if (sp.expired(abort_word)) { bad = true; break; }
             }
-            if (__all(ok)) break;
-            if (sp.expired(abort_word)) { bad = true; break; }
+            if (__any(bad)) break;
         }
+        if (part == 0) tot[0] = t; else tot[1] = t;
         if (__any(bad)) break;
     }
     return !__any(bad);
@@ -466,9 +461,9 @@ __device__ __forceinline__ bool poll_totals(int nb, bool fast, bool act, const u
 
 // ---- per-R storage types ------------------------------------------------------------------
 template <int R> struct Slice;
-template <> struct Slice<1> { using own_t = uint8_t;  using ld_t = uint16_t; };
-template <> struct Slice<2> { using own_t = uint16_t; using ld_t = uint32_t; };
-template <> struct Slice<4> { using own_t = uint32_t; using ld_t = unsigned long long; };
+template <> struct Slice<1> { using own_t = uint8_t; };
+template <> struct Slice<2> { using own_t = uint16_t; };
+template <> struct Slice<4> { using own_t = uint32_t; };
 
 // Diagnostic build only (-DGM_SWEEP_PROF): thread 0 of every workgroup accumulates wall-clock
 // ticks (100 MHz) per phase; workgroups 0 and W/2 write them to stats[4..]/stats[12..].
@@ -485,29 +480,70 @@ template <> struct Slice<4> { using own_t = uint32_t; using ld_t = unsigned long
 #define PROF(i) do { } while (0)
 #endif
 
-template <int R>
+// ---- phase A building blocks --------------------------------------------------------------
+// Eight dot4 of one genotype byte's a-values (4 x int8) against the digit-plane record that lane
+// J of this 16-lane row holds (DPP row_newbcast).  All lanes of the row must be active.
+#define GM_DOT8(J, A4, ACC, PA, PB)                                                                   \
+    asm("s_nop 1\n\t"                                                                        \
+                 "v_dot4c_i32_i8_dpp %0, %8, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"  \
+                 "v_dot4c_i32_i8_dpp %1, %9, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"  \
+                 "v_dot4c_i32_i8_dpp %2, %10, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_dot4c_i32_i8_dpp %3, %11, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_dot4c_i32_i8_dpp %4, %12, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_dot4c_i32_i8_dpp %5, %13, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_dot4c_i32_i8_dpp %6, %14, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
+                 "v_dot4c_i32_i8_dpp %7, %15, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf"     \
+                 : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]),                            \
+                   "+v"(ACC[4]), "+v"(ACC[5]), "+v"(ACC[6]), "+v"(ACC[7])                             \
+                 : "v"(PA.x), "v"(PA.y), "v"(PA.z), "v"(PA.w), "v"(PB.x), "v"(PB.y), "v"(PB.z), "v"(PB.w), "v"(A4))
+
+__device__ __forceinline__ uint32_t chunk_byte(const uint4& w, int j) {      // byte j (0..15) of a 16-byte chunk
+    const uint32_t ww = j < 4 ? w.x : (j < 8 ? w.y : (j < 12 ? w.z : w.w));
+    return (ww >> (8 * (j & 3))) & 0xffu;
+}
+// four signed base-256 digits of x (|x| <= 2^30) as the four bytes of the result
+__device__ __forceinline__ uint32_t signed_digits(int x) { return ((uint32_t)x + 0x00808080u) ^ 0x00808080u; }
+// byte p of z0..z3 -> one dword (digit plane p of four individuals)
+__device__ __forceinline__ uint4 digit_planes(uint32_t z0, uint32_t z1, uint32_t z2, uint32_t z3) {
+    const uint32_t lo01 = __builtin_amdgcn_perm(z1, z0, 0x05010400u);   // z0.b0 z1.b0 z0.b1 z1.b1
+    const uint32_t hi01 = __builtin_amdgcn_perm(z1, z0, 0x07030602u);   // z0.b2 z1.b2 z0.b3 z1.b3
+    const uint32_t lo23 = __builtin_amdgcn_perm(z3, z2, 0x05010400u);
+    const uint32_t hi23 = __builtin_amdgcn_perm(z3, z2, 0x07030602u);
+    uint4 r;
+    r.x = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);               // b0 of z0 z1 z2 z3
+    r.y = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);               // b1
+    r.z = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);               // b2
+    r.w = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);               // b3
+    return r;
+}
+
+template <int R, bool FAST>
 __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using own_t = typename Slice<R>::own_t;          // this thread's R bytes of a column
-    using ld_t = typename Slice<R>::ld_t;            // a loader thread's 2R bytes
+    using GE = Geo<R>;
     constexpr int NI = 4 * R;                        // individuals per thread
-    constexpr ld_t ODD = (ld_t)0x5555555555555555ull;
-    constexpr int RPOS = ring_pos(R), BMAX = bmax(R);
+    constexpr int SB = GE::SB, CPP = GE::CPP, RPOS = GE::RPOS, PPI = GE::PPI, PFN = GE::PFN, PFG = GE::PFG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
     const int W = a.W, K = a.K, G = a.G;
+    constexpr bool fast = FAST;                      // exchange layout, fixed per launch (host: all_nomiss)
+    const int BMAX = fast ? GE::BMAXF : GE::BMAXG;
 
     const double* s_val = reinterpret_cast<const double*>(smem + L_VAL);
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     uint32_t* s_rng0 = reinterpret_cast<uint32_t*>(smem + L_RNG0);
     uint32_t* s_rng1 = reinterpret_cast<uint32_t*>(smem + L_RNG1);
     int* s_cass = reinterpret_cast<int*>(smem + L_CASS);
-    double* s_wsum = reinterpret_cast<double*>(smem + L_WSUM);
+    unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(smem + L_SUM);
     double* s_red = reinterpret_cast<double*>(smem + L_RED);
+    double* s_wsq = reinterpret_cast<double*>(smem + L_WSQ);
     double* s_tab = reinterpret_cast<double*>(smem + L_TAB);
-    double* blut = reinterpret_cast<double*>(smem + L_BLUT);
+    uint32_t* lut_a = reinterpret_cast<uint32_t*>(smem + L_LUTA);
+    uint32_t* lut_b = reinterpret_cast<uint32_t*>(smem + L_LUTB);
+    char* planes = smem + L_PLN;
     const bool tab_in_lds = G * (1 + 3 * K) <= TAB_LDS;
     const double* tabp = tab_in_lds ? s_tab : a.sigmag;   // sigmag|denom|logpi|mhl, contiguous
-    char* ring = smem + L_RING;
+    char* ring = smem + l_ring<R>();
     unsigned* abort_word = a.cnt + 64;
     unsigned long long* Pg = reinterpret_cast<unsigned long long*>(a.P);
     unsigned long long* Ttg = reinterpret_cast<unsigned long long*>(a.Tt);
@@ -516,7 +552,16 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     for (int i = tid; i < G * K; i += SW_TPB) s_cass[i] = 0;
     if (tab_in_lds)
         for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];
-    for (int i = tid; i < 1024; i += SW_TPB) blut[blut_row((uint32_t)i >> 2) * 4 + (i & 3)] = code_a(((i >> 2) >> (2 * (i & 3))) & 3);
+    {   // the reference's dotp_lut_a / dotp_lut_b rows (src/dotp_lut.hpp) as 4 x int8 per genotype byte
+        uint32_t wa = 0, wb = 0;
+        for (int j = 0; j < 4; j++) {
+            const int c = (tid >> (2 * j)) & 3;
+            wa |= (uint32_t)code_a(c) << (8 * j);
+            wb |= (uint32_t)code_b(c) << (8 * j);
+        }
+        lut_a[tid] = wa; lut_b[tid] = wb;
+    }
+    s_sum[tid] = 0ull;
 #ifdef GM_SWEEP_PROF
     if (tid < 8) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[tid] = 0ull;
 #endif
@@ -525,7 +570,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         ctl[C_RNGERR] = 0;
         ctl[C_BAD] = 0;
         ctl[C_EMA] = 16 * a.batch_init / 2;
-        ctl[C_NBNEXT] = a.batch_init;
+        ctl[C_NBNEXT] = a.batch_init < 16 ? 16 : (a.batch_init > BMAX ? BMAX : a.batch_init);
     }
     __syncthreads();
     block_advance(s_rng0, s_rng1, ctl, false);       // S1 = twist(S0)
@@ -533,7 +578,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // ---- this thread's slice of the residual ------------------------------------------
     const size_t b0 = ((size_t)wg * SW_TPB + tid) * R;
     const bool valid = b0 < a.stride;
-    double eps[NI], q1[NI], q2[NI];
+    double eps[NI];
     if (valid) {
 #pragma unroll
         for (int i = 0; i < NI; i++) eps[i] = a.eps[4 * b0 + i];
@@ -541,84 +586,176 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #pragma unroll
         for (int i = 0; i < NI; i++) eps[i] = 0.0;
     }
+    // split the thread's residuals, park their digit planes in LDS, leave the wavefront's sum of
+    // q1 / q2 in s_wsq (readers: after the next barrier)
+    auto refresh_planes = [&]() {
+        double sq1 = 0.0, sq2 = 0.0;
 #pragma unroll
-    for (int i = 0; i < NI; i++) split2(eps[i], q1[i], q2[i]);
-    double sq1 = 0.0, sq2 = 0.0;                     // this thread's sum of q1 / q2 (exact)
+        for (int k = 0; k < R; k++) {
+            uint32_t z1[4], z2[4];
 #pragma unroll
-    for (int i = 0; i < NI; i++) { sq1 += q1[i]; sq2 += q2[i]; }
+            for (int j = 0; j < 4; j++) {
+                double q1, q2;
+                split2(eps[4 * k + j], q1, q2);
+                sq1 += q1; sq2 += q2;
+                z1[j] = signed_digits((int)(q1 * 0x1p22));      // exact: q1 is a multiple of 2^-22, |q1| <= 2^8
+                z2[j] = signed_digits((int)(q2 * 0x1p53));      // exact: q2 is a multiple of 2^-53, |q2| <= 2^-23
+            }
+            uint4* rec = reinterpret_cast<uint4*>(planes + ((size_t)tid * R + k) * 32);
+            rec[0] = digit_planes(z1[0], z1[1], z1[2], z1[3]);
+            rec[1] = digit_planes(z2[0], z2[1], z2[2], z2[3]);
+        }
+        const double r2 = reduce2(sq1, sq2);
+        if (lane == 0) s_wsq[wave * 2 + 0] = r2;
+        if (lane == 32) s_wsq[wave * 2 + 1] = r2;
+    };
+    refresh_planes();
 
-    // ---- loader role (wavefronts 1-2): 2R bytes of every upcoming column ----------------
+    // ---- loader role (wavefronts 1-3): one 16-byte chunk of PFN upcoming columns per round -----
     // codes of NA / out-of-range individuals are forced to 01 (a = b = 0, update value 0)
-    const bool loader = wave == 1 || wave == 2;
+    const bool loader = wave != 0;                    // wavefront 0 polls: its loads must not queue behind prefetches
     const int lt = loader ? tid - 64 : 0;
-    const size_t cb_true = (size_t)wg * SW_TPB * R + (size_t)lt * 2 * R;
+    const int lci = lt % CPP, lpj = lt / CPP;         // chunk of the slice, position within a load instruction
+    const size_t cb_true = (size_t)wg * SB + (size_t)lci * 16;
     const bool lvalid = loader && cb_true < a.stride;
-    const size_t cb = lvalid ? cb_true : 0;           // out-of-range lanes read column byte 0 and mask it away
-    ld_t lkeep = 0, lforce = ODD;
+    const size_t cb = lvalid ? cb_true : 0;           // out-of-range lanes read column bytes 0..15 and mask them away
+    uint4 lkeep = make_uint4(0u, 0u, 0u, 0u), lforce = make_uint4(0x55555555u, 0x55555555u, 0x55555555u, 0x55555555u);
     if (lvalid) {
-        const ld_t nam = *reinterpret_cast<const ld_t*>(a.namask2 + cb);
+        const uint4 nam = *reinterpret_cast<const uint4*>(a.namask2 + cb);
         lkeep = nam;
-        lforce = (ld_t)(~nam) & ODD;
+        lforce = make_uint4(~nam.x & 0x55555555u, ~nam.y & 0x55555555u, ~nam.z & 0x55555555u, ~nam.w & 0x55555555u);
     }
-    ld_t pf[PFN];
+    auto masked = [&](const uint4& v) {
+        return make_uint4((v.x & lkeep.x) | lforce.x, (v.y & lkeep.y) | lforce.y, (v.z & lkeep.z) | lforce.z, (v.w & lkeep.w) | lforce.w);
+    };
+    auto ring_chunk = [&](int p, int chunk) -> uint4* {   // 16-byte chunk `chunk` of order position p
+        return reinterpret_cast<uint4*>(ring + (size_t)((unsigned)p % (unsigned)RPOS) * SB + 16 * (chunk ^ (p & (CPP - 1))));
+    };
+    uint4 pf[PFN];
+    int pos = 0;
     int hi = 0;                                       // ring holds order positions [pos, hi)
+    int npf = 0;                                      // positions [hi, hi + npf) are in flight / in registers
 
-    // synchronous ring fill of positions [from, to) (start-up and the rare slow path)
+    // synchronous ring fill of positions [from, to) (start-up and the rare slow path; kept small)
     auto fill = [&](int from, int to) {
-        for (int p0 = from; p0 < to; p0 += PFN) {
-            const int n = (to - p0) < PFN ? (to - p0) : PFN;
-            if (loader) {
-#pragma unroll
-                for (int i = 0; i < PFN; i++) {            // unconditional loads (clamped index): nothing waits on a select
-                    const int pi = p0 + i < a.M ? p0 + i : a.M - 1;
-                    pf[i] = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[pi] * a.stride + cb);
-                }
-#pragma unroll
-                for (int i = 0; i < PFN; i++) pf[i] = (pf[i] & lkeep) | lforce;
-#pragma unroll
-                for (int i = 0; i < PFN; i++)
-                    if (i < n) *reinterpret_cast<ld_t*>(ring + (size_t)((p0 + i) & (RPOS - 1)) * (SW_TPB * R) + (size_t)lt * 2 * R) = pf[i];
+        if (loader) {
+#pragma unroll 1
+            for (int p = from + lpj; p < to; p += PPI) {
+                const uint4 v = *reinterpret_cast<const uint4*>(a.bed + (size_t)a.order[p] * a.stride + cb);
+                *ring_chunk(p, lci) = masked(v);
             }
         }
         __syncthreads();
     };
+    // request the slices of positions [hi, want) (at most PFN*PPI); they stay in registers until commit
+    auto prefetch_issue = [&](int want) {
+        if (want > a.M) want = a.M;
+        npf = want - hi;
+        if (npf > PFN * PPI) npf = PFN * PPI;
+        if (npf < 0) npf = 0;
+        if (loader) {
+            // groups of PFG loads behind wave-uniform branches: only about npf/PPI loads are issued and
+            // none waits on a select (indices are clamped, surplus positions are dropped at commit).
+            // All marker ids are requested before the first column load: a wait for ids issued
+            // behind column loads would serialise the groups on HBM latency (loads return in order).
+            int idx[PFN];
+#pragma unroll
+            for (int c8 = 0; c8 < PFN; c8 += PFG) {
+                if (c8 * PPI < npf) {
+#pragma unroll
+                    for (int i = c8; i < c8 + PFG; i++) {
+                        const int p = hi + i * PPI + lpj;
+                        idx[i] = a.order[p < a.M ? p : a.M - 1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int c8 = 0; c8 < PFN; c8 += PFG) {
+                if (c8 * PPI < npf) {
+#pragma unroll
+                    for (int i = c8; i < c8 + PFG; i++)
+                        pf[i] = *reinterpret_cast<const uint4*>(a.bed + (size_t)idx[i] * a.stride + cb);
+                }
+            }
+        }
+    };
+    // park the requested slices in the ring as far as the window [pos, pos + RPOS) allows (the rest
+    // is dropped and requested again); readers see them after the next barrier.  Called a full
+    // round after the issue, so nobody waits for HBM.
+    auto prefetch_commit = [&]() {
+        int nc = pos + RPOS - hi;
+        if (nc > npf) nc = npf;
+        if (nc < 0) nc = 0;
+        if (loader) {
+#pragma unroll
+            for (int c8 = 0; c8 < PFN; c8 += PFG) {
+                if (c8 * PPI < nc) {
+#pragma unroll
+                    for (int i = c8; i < c8 + PFG; i++) {
+                        const int o = i * PPI + lpj;
+                        if (o < nc) *ring_chunk(hi + o, lci) = masked(pf[i]);
+                    }
+                }
+            }
+        }
+        hi += nc;
+        npf = 0;
+    };
+    auto ensure = [&](int upto) {                      // slow path: ring must hold [pos, upto)
+        if (hi < upto) prefetch_commit();
+        if (hi < upto) { fill(hi, upto); hi = upto; }
+    };
 
     // ---- per-marker inputs of the sampling step (marker id, group, previous effect, mave, msig):
     // wavefront 3 fetches them for upcoming order positions (dependent global loads) one
-    // iteration ahead and parks them in a 128-position LDS ring, so a restart never waits on them.
+    // round ahead and parks them in a 256-position LDS ring, so a restart never waits on them.
     int* mr_m = reinterpret_cast<int*>(smem + L_META);
     int* mr_g = mr_m + META_POS;
     double* mr_beta = reinterpret_cast<double*>(mr_g + META_POS);
     double* mr_mave = mr_beta + META_POS;
     double* mr_msig = mr_mave + META_POS;
     int mhi = 0, npm = 0;                             // meta ring holds positions [pos, mhi)
-    int pm_m = 0, pm_g = 0;
-    double pm_beta = 0.0, pm_mave = 0.0, pm_msig = 1.0;
-    auto meta_issue = [&](int base_pos) {
-        int want = base_pos + META_POS < a.M ? base_pos + META_POS : a.M;
+    int pm_m[2] = {0, 0}, pm_g[2] = {0, 0};
+    double pm_beta[2] = {0.0, 0.0}, pm_mave[2] = {0.0, 0.0}, pm_msig[2] = {1.0, 1.0};
+    auto meta_issue = [&](int want) {
+        if (want > a.M) want = a.M;
         npm = want - mhi;
-        if (npm > 64) npm = 64;
+        if (npm > 128) npm = 128;
         if (npm < 0) npm = 0;
         if (wave == 3) {
-            const int pi = mhi + lane < a.M ? mhi + lane : a.M - 1;
-            pm_m = a.order[pi];
-            pm_g = a.group[pm_m];
-            pm_beta = a.betas_in[pm_m];
-            pm_mave = a.mave[pm_m];
-            pm_msig = a.msig[pm_m];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (64 * h < npm) {
+                    const int p = mhi + 64 * h + lane;
+                    const int pi = p < a.M ? p : a.M - 1;
+                    pm_m[h] = a.order[pi];
+                    pm_g[h] = a.group[pm_m[h]];
+                    pm_beta[h] = a.betas_in[pm_m[h]];
+                    pm_mave[h] = a.mave[pm_m[h]];
+                    pm_msig[h] = a.msig[pm_m[h]];
+                }
+            }
         }
     };
     auto meta_commit = [&]() {
-        if (wave == 3 && lane < npm) {
-            const int sl = (mhi + lane) & (META_POS - 1);
-            mr_m[sl] = pm_m; mr_g[sl] = pm_g; mr_beta[sl] = pm_beta; mr_mave[sl] = pm_mave; mr_msig[sl] = pm_msig;
+        int nc = pos + META_POS - mhi;
+        if (nc > npm) nc = npm;
+        if (nc < 0) nc = 0;
+        if (wave == 3) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (64 * h + lane < nc) {
+                    const int sl = (mhi + 64 * h + lane) & (META_POS - 1);
+                    mr_m[sl] = pm_m[h]; mr_g[sl] = pm_g[h]; mr_beta[sl] = pm_beta[h]; mr_mave[sl] = pm_mave[h]; mr_msig[sl] = pm_msig[h];
+                }
+            }
         }
-        mhi += npm;
+        mhi += nc;
         npm = 0;
     };
-    auto ensure_meta = [&](int base_pos, int upto) {   // slow path (uniform): meta ring must hold [.., upto)
+    auto ensure_meta = [&](int upto) {                 // slow path (uniform): meta ring must hold [.., upto)
         if (mhi < upto) meta_commit();
-        while (mhi < upto) { meta_issue(base_pos); meta_commit(); }
+        while (mhi < upto) { meta_issue(upto); meta_commit(); }
     };
 
     // ---- the marker loop, software-pipelined over exchange generations -----------------------
@@ -628,8 +765,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // the reducers); otherwise it is discarded and a fresh batch starts after the stopping
     // marker.  Generation g uses tag g+1 and buffer g&1; a buffer is rewritten only after every
     // workgroup has sampled the generation that used it.
-    struct Batch { int p0, nb, nv; unsigned gen; bool fast; };
-    int pos = 0;
+    struct Batch { int p0, nb, nv; unsigned gen; };
     unsigned gen_next = 0;
     long long n_upd = 0, n_batch = 0, n_disc = 0;
     int max_nb = 0;
@@ -638,111 +774,93 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_amdgcn_s_memrealtime();
 #endif
-    int npf = 0;
-
-    auto prefetch_issue = [&](int limit) {
-        int want = limit < a.M ? limit : a.M;
-        if (want > pos + RPOS) want = pos + RPOS;
-        npf = want - hi;
-        if (npf > PFN) npf = PFN;
-        if (npf < 0) npf = 0;
-        if (loader) {
-            // chunks of 8 behind wave-uniform branches: only about npf loads are issued, none waits
-            // on a select (indices are clamped, surplus lanes of the last chunk are dropped at commit)
-#pragma unroll
-            for (int c8 = 0; c8 < PFN; c8 += 8) {
-                if (c8 < npf) {
-#pragma unroll
-                    for (int i = c8; i < c8 + 8; i++) {
-                        const int pi = hi + i < a.M ? hi + i : a.M - 1;
-                        pf[i] = *reinterpret_cast<const ld_t*>(a.bed + (size_t)a.order[pi] * a.stride + cb);
-                    }
-                }
-            }
-        }
-    };
-    // park the slices fetched by the previous prefetch_issue in the ring (readers see them after
-    // the next barrier).  Called late -- right before the next issue -- so nobody waits for HBM.
-    auto prefetch_commit = [&]() {
-        if (loader) {
-#pragma unroll
-            for (int i = 0; i < PFN; i++)
-                if (i < npf) *reinterpret_cast<ld_t*>(ring + (size_t)((hi + i) & (RPOS - 1)) * (SW_TPB * R) + (size_t)lt * 2 * R) = (pf[i] & lkeep) | lforce;
-        }
-        hi += npf;
-        npf = 0;
-    };
-    auto ensure = [&](int upto) {                      // slow path: ring must hold [pos, upto)
-        if (hi < upto) prefetch_commit();
-        if (hi < upto) { fill(hi, upto); hi = upto; }
-    };
 
     // phase A for positions [b.p0, b.p0 + b.nb) (slices already in the ring) + publish
-    auto compute_publish = [&](Batch& b, LaneIn& li) {
-        lds_barrier();                                // ring writes are visible (no vmcnt drain)
-        li = LaneIn{0, 0, 0.0, 0.0, 1.0};
-        if (wave == 0 && lane < b.nb) {
-            const int sl = (b.p0 + lane) & (META_POS - 1);
-            li.m = mr_m[sl]; li.g = mr_g[sl]; li.beta_old = mr_beta[sl]; li.mave = mr_mave[sl]; li.msig = mr_msig[sl];
-        }
-        const bool fast = a.all_nomiss != 0;          // exchange layout, fixed per launch
+    auto compute_publish = [&](Batch& b, LaneIn (&li)[2]) {
+        lds_barrier();                                // ring / plane / meta writes are visible (no vmcnt drain)
         const int nb = b.nb, p0 = b.p0;
-        max_nb = nb > max_nb ? nb : max_nb;
-        if (fast) {
-            // b == 1 wherever the residual is non-zero: only the a-sums depend on the marker
-            for (int g0 = 0; g0 < nb; g0 += 2 * SW_GB) {
-                double acc[32];
 #pragma unroll
-                for (int gm = 0; gm < 2 * SW_GB; gm++) {
-                    // unconditional ring read: slots past the batch hold finite junk that nobody consumes
-                    const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((p0 + g0 + gm) & (RPOS - 1)) * (SW_TPB * R) + (size_t)tid * R);
-                    double sa1 = 0.0, sa2 = 0.0;
-#pragma unroll
-                    for (int k = 0; k < R; k++) {                  // one table row per genotype byte
-                        const double* row = blut + blut_row((wd >> (8 * k)) & 0xFFu) * 4;
-                        const double2 a01 = *reinterpret_cast<const double2*>(row);
-                        const double2 a23 = *reinterpret_cast<const double2*>(row + 2);
-                        sa1 = fma_(a01.x, q1[4 * k + 0], sa1); sa2 = fma_(a01.x, q2[4 * k + 0], sa2);
-                        sa1 = fma_(a01.y, q1[4 * k + 1], sa1); sa2 = fma_(a01.y, q2[4 * k + 1], sa2);
-                        sa1 = fma_(a23.x, q1[4 * k + 2], sa1); sa2 = fma_(a23.x, q2[4 * k + 2], sa2);
-                        sa1 = fma_(a23.y, q1[4 * k + 3], sa1); sa2 = fma_(a23.y, q2[4 * k + 3], sa2);
-                    }
-                    acc[gm * 2 + 0] = sa1; acc[gm * 2 + 1] = sa2;
-                }
-                const double r = reduce32(acc, lane);
-                if ((lane & 1) == 0) s_wsum[wave * SW_VMAX + g0 * 2 + (lane >> 1)] = r;
+        for (int h = 0; h < 2; h++) {
+            li[h] = LaneIn{0, 0, 0.0, 0.0, 1.0};
+            if (wave == 0 && lane + 64 * h < nb) {
+                const int sl = (p0 + lane + 64 * h) & (META_POS - 1);
+                li[h].m = mr_m[sl]; li[h].g = mr_g[sl]; li[h].beta_old = mr_beta[sl]; li[h].mave = mr_mave[sl]; li[h].msig = mr_msig[sl];
             }
-            const double r2 = reduce2(sq1, sq2);
-            if (lane == 0) s_wsum[wave * SW_VMAX + 2 * nb] = r2;
-            if (lane == 32) s_wsum[wave * SW_VMAX + 2 * nb + 1] = r2;
-        } else {
-            for (int g0 = 0; g0 < nb; g0 += SW_GB) {
-                double acc[32];
+        }
+        max_nb = nb > max_nb ? nb : max_nb;
+        // thread -> (marker mk of the batch, sub-slice sub): nbp = batch size rounded up to a power of two >= 16
+        int lg = 4;
+        while ((1 << lg) < nb) lg++;
+        const int nbp = 1 << lg;
+        const int mk = tid & (nbp - 1), sub = tid >> lg;
+        const int nch = (CPP << lg) / SW_TPB;          // 16-byte chunks per thread (>= 1)
+        const int pl = p0 + (mk < nb ? mk : nb - 1);   // idle lanes shadow the last marker (their sums are dropped)
+        const char* slice = ring + (size_t)((unsigned)pl % (unsigned)RPOS) * SB;
+        const int swz = pl & (CPP - 1);
+        const char* prec = planes + ((size_t)sub * nch * 16 + (lane & 15)) * 32;
+        int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int bcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // software pipeline over the thread's 16-byte chunks: the a-values (LUT reads) of chunk c+1, its
+        // plane record and the genotype bytes of chunk c+2 are requested before the 128 dot4 of chunk c
+        auto chunk_at = [&](int c) { return *reinterpret_cast<const uint4*>(slice + 16 * ((sub * nch + (c < nch ? c : nch - 1)) ^ swz)); };
+        auto rec_at = [&](int c, int half) { return *reinterpret_cast<const uint4*>(prec + (size_t)(c < nch ? c : nch - 1) * 512 + 16 * half); };
+        uint4 w1 = chunk_at(0);
+        uint4 pa = rec_at(0, 0), pb = rec_at(0, 1);
+        uint32_t a4[16], b4[16];
 #pragma unroll
-                for (int gm = 0; gm < SW_GB; gm++) {
-                    const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((p0 + g0 + gm) & (RPOS - 1)) * (SW_TPB * R) + (size_t)tid * R);
-                    double sa1 = 0.0, sa2 = 0.0, sb1 = 0.0, sb2 = 0.0;
-                    const uint32_t nw = ~wd;
-                    const uint32_t present = ~(wd & ~(wd >> 1));               // bit 2i clear only for code 01
+        for (int j = 0; j < 16; j++) {
+            const uint32_t e = chunk_byte(w1, j);
+            a4[j] = lut_a[e];
+            if (!FAST) b4[j] = lut_b[e];
+        }
+        w1 = chunk_at(1);
+        for (int c = 0; c < nch; c++) {
+            const uint4 pan = rec_at(c + 1, 0), pbn = rec_at(c + 1, 1);
+            uint32_t a4n[16], b4n[16];
 #pragma unroll
-                    for (int i = 0; i < NI; i++) {
-                        const double av = code_a_bits(wd, nw, i), bv = code_b_bits(present, i);
-                        sa1 = fma_(av, q1[i], sa1); sa2 = fma_(av, q2[i], sa2);
-                        sb1 = fma_(bv, q1[i], sb1); sb2 = fma_(bv, q2[i], sb2);
-                    }
-                    acc[gm * 4 + 0] = sa1; acc[gm * 4 + 1] = sa2; acc[gm * 4 + 2] = sb1; acc[gm * 4 + 3] = sb2;
-                }
-                const double r = reduce32(acc, lane);
-                if ((lane & 1) == 0) s_wsum[wave * SW_VMAX + g0 * 4 + (lane >> 1)] = r;
+            for (int j = 0; j < 16; j++) {
+                const uint32_t e = chunk_byte(w1, j);
+                a4n[j] = lut_a[e];
+                if (!FAST) b4n[j] = lut_b[e];
+            }
+            w1 = chunk_at(c + 2);
+#define GM_STEP(J) { GM_DOT8(J, a4[J], acc, pa, pb); if (!FAST) { GM_DOT8(J, b4[J], bcc, pa, pb); } }
+            GM_STEP(0) GM_STEP(1) GM_STEP(2) GM_STEP(3) GM_STEP(4) GM_STEP(5) GM_STEP(6) GM_STEP(7)
+            GM_STEP(8) GM_STEP(9) GM_STEP(10) GM_STEP(11) GM_STEP(12) GM_STEP(13) GM_STEP(14) GM_STEP(15)
+#undef GM_STEP
+            pa = pan; pb = pbn;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { a4[j] = a4n[j]; if (!FAST) b4[j] = b4n[j]; }
+        }
+        if (mk < nb) {                                // digits -> 64-bit sums; sub-slices meet in LDS (integer: exact, any order)
+            const long long s1 = (long long)acc[0] + ((long long)acc[1] << 8) + ((long long)acc[2] << 16) + ((long long)acc[3] << 24);
+            const long long s2 = (long long)acc[4] + ((long long)acc[5] << 8) + ((long long)acc[6] << 16) + ((long long)acc[7] << 24);
+            if (fast) {
+                atomicAdd(&s_sum[2 * mk + 0], (unsigned long long)s1);
+                atomicAdd(&s_sum[2 * mk + 1], (unsigned long long)s2);
+            } else {
+                const long long u1 = (long long)bcc[0] + ((long long)bcc[1] << 8) + ((long long)bcc[2] << 16) + ((long long)bcc[3] << 24);
+                const long long u2 = (long long)bcc[4] + ((long long)bcc[5] << 8) + ((long long)bcc[6] << 16) + ((long long)bcc[7] << 24);
+                atomicAdd(&s_sum[4 * mk + 0], (unsigned long long)s1);
+                atomicAdd(&s_sum[4 * mk + 1], (unsigned long long)s2);
+                atomicAdd(&s_sum[4 * mk + 2], (unsigned long long)u1);
+                atomicAdd(&s_sum[4 * mk + 3], (unsigned long long)u2);
             }
         }
         __syncthreads();
         const int nv = fast ? 2 * nb + 2 : 4 * nb;
         if (tid < nv) {
-            const double tot = s_wsum[tid] + s_wsum[SW_VMAX + tid] + s_wsum[2 * SW_VMAX + tid] + s_wsum[3 * SW_VMAX + tid];
+            double tot;
+            if (fast && tid >= 2 * nb) {
+                const int w2 = tid - 2 * nb;
+                tot = s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2];
+            } else {
+                // |sum| < 2^53 grid units: the conversion and the power-of-two scaling are exact
+                tot = (double)(long long)s_sum[tid] * ((tid & 1) ? 0x1p-53 : 0x1p-22);
+                s_sum[tid] = 0ull;
+            }
             put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)tid * a.Wpad + wg), b.gen + 1u, tot);
         }
-        b.fast = fast;
         b.nv = nv;
     };
 
@@ -773,15 +891,16 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         return bad;
     };
 
-    Batch cur{0, 0, 0, 0u, false}, nxt{0, 0, 0, 0u, false}, tb{0, 0, 0, 0u, false};
-    LaneIn li_cur{0, 0, 0.0, 0.0, 1.0}, li_nxt{0, 0, 0.0, 0.0, 1.0}, tl{0, 0, 0.0, 0.0, 1.0};
+    Batch cur{0, 0, 0, 0u}, nxt{0, 0, 0, 0u}, tb{0, 0, 0, 0u};
+    LaneIn li_cur[2], li_nxt[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) li_cur[h] = li_nxt[h] = LaneIn{0, 0, 0.0, 0.0, 1.0};
     bool bad = false;
     {
-        int first = 3 * BMAX < a.M ? 3 * BMAX : a.M;
-        if (first > RPOS) first = RPOS;
+        const int first = RPOS < a.M ? RPOS : a.M;
         fill(0, first);
         hi = first;
-        ensure_meta(0, META_POS < a.M ? META_POS : a.M);
+        ensure_meta(META_POS < a.M ? META_POS : a.M);
         __syncthreads();
     }
     // One compute site and one reduce site serve the three cases (first batch, restart after a
@@ -798,53 +917,57 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             tb.p0 = pos; tb.nb = nb0; tb.gen = gen_next++;
             do_compute = true;
         } else if (ctl[C_EMA] >= a.spec_factor16 * cur.nb) {   // speculate only when the recent run length (1/16 units)
-            const int p1 = pos + cur.nb;              // is >= 1.5 batches: P(no residual update) >~ 1/2
+            const int p1 = pos + cur.nb;              // is long enough: P(no residual update) >~ 1/2
             if (p1 < a.M) {
                 int nb1 = ctl[C_NBNEXT];
                 if (nb1 > a.M - p1) nb1 = a.M - p1;
-                tb.p0 = p1; tb.nb = nb1; tb.gen = gen_next++;
-                do_compute = true;
+                if (nb1 > pos + RPOS - p1) nb1 = pos + RPOS - p1;   // both batches live in the ring
+                if (nb1 > 0) {
+                    tb.p0 = p1; tb.nb = nb1; tb.gen = gen_next++;
+                    do_compute = true;
+                }
             }
         }
         if (do_compute) {
             ensure(tb.p0 + tb.nb);
-            ensure_meta(pos, tb.p0 + tb.nb);
-            compute_publish(tb, tl);
+            ensure_meta(tb.p0 + tb.nb);
+            if (restart) compute_publish(tb, li_cur); else compute_publish(tb, li_nxt);
         }
         if (restart) TRACE(1);
         PROF(1);   // dots + publish (restart: on the critical path; speculative: overlaps the exchange)
         if (restart) {
-            cur = tb; li_cur = tl;
+            cur = tb;
             restart = false;
             need_reduce = true;
             continue;
         }
         have_next = do_compute;
-        if (have_next) { nxt = tb; li_nxt = tl; }
-        prefetch_commit();
-        meta_commit();
-        prefetch_issue(pos + cur.nb + (have_next ? nxt.nb : 0) + BMAX);
-        meta_issue(pos);
-        PROF(2);   // ring write of the previous prefetch + issue of the next
+        if (have_next) nxt = tb;
+        // request the slices / sampling inputs the ring can take once the current batch has been
+        // walked to its end; wavefronts 1-3 idle through the sampling step below, which hides the
+        // marker-id round trip and most of the HBM latency
+        prefetch_issue(pos + cur.nb + RPOS);
+        meta_issue(pos + cur.nb + META_POS);
+        PROF(2);   // prefetch issue
 
         // ---- sampling step of the current batch (wavefront 0, every workgroup, identical inputs)
         if (wave == 0) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
-            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-            const bool okw = poll_totals(cur.nb, cur.fast, lane < cur.nb, Tb, cur.gen + 1u, t0, t1, t2, t3, abort_word);
+            Totals tot[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+            const bool okw = poll_totals(cur.nb, fast, Tb, cur.gen + 1u, tot, abort_word);
             TRACE(3);
             PROF(4);   // wait for the totals
             bad |= !okw;
             if (okw) {
                 switch (K) {
-                    case 2: sample_batch<2>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 3: sample_batch<3>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 4: sample_batch_body<4>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 5: sample_batch<5>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 6: sample_batch<6>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 7: sample_batch<7>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    default: sample_batch<8>(cur.nb, BMAX, a.all_nomiss ? 2 * SW_GB : SW_GB, a.nb_factor16, G, smem, tabp, li_cur, t0, t1, t2, t3, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 2: sample_batch<2>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 3: sample_batch<3>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 4: sample_batch_body<4>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 5: sample_batch<5>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 6: sample_batch<6>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    case 7: sample_batch<7>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    default: sample_batch<8>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
                 }
             }
         }
@@ -860,27 +983,30 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         const bool upd = ctl[C_UPD] != 0;
         if (upd) {
             n_upd++;
-            const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((pos + ctl[C_SUPD]) & (RPOS - 1)) * (SW_TPB * R) + (size_t)tid * R);
+            const int ps = pos + ctl[C_SUPD];
+            const int ob = tid * R;                    // this thread's bytes of the slice
+            const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((unsigned)ps % (unsigned)RPOS) * SB +
+                                                                16 * ((ob >> 4) ^ (ps & (CPP - 1))) + (ob & 15));
 #pragma unroll
-            for (int i = 0; i < NI; i++) {
-                eps[i] += s_val[(wd >> (2 * i)) & 3u];
-                split2(eps[i], q1[i], q2[i]);
-            }
-            sq1 = 0.0; sq2 = 0.0;
-#pragma unroll
-            for (int i = 0; i < NI; i++) { sq1 += q1[i]; sq2 += q2[i]; }
+            for (int i = 0; i < NI; i++) eps[i] += s_val[(wd >> (2 * i)) & 3u];
+            refresh_planes();
         }
         pos += n_done;
         n_batch++;
         TRACE(6);
-        PROF(6);   // residual update + ring write
+        PROF(6);   // residual update + plane refresh
+        // the sampled batch has released its ring slots: park what was requested before the sampling step
+        const bool will_restart = upd || n_done < cur.nb || !have_next;
+        prefetch_commit();
+        meta_commit();
+        PROF(3);   // ring write of the prefetch
         if (ctl[C_CURSOR] >= 624) block_advance(s_rng0, s_rng1, ctl, true);
-        if (upd || n_done < cur.nb || !have_next) {   // the speculative batch (if any) is stale: restart
+        if (will_restart) {                           // the speculative batch (if any) is stale: restart
             if (have_next) n_disc++;
             restart = true;
         } else {                                      // promote: its partials are already at the reducers
             cur = nxt;
-            li_cur = li_nxt;
+            li_cur[0] = li_nxt[0]; li_cur[1] = li_nxt[1];
             need_reduce = true;
         }
     }
@@ -925,12 +1051,15 @@ int sweep_pick_R(size_t stride, int max_wg, int* W_out) {
     return -1;
 }
 
-template <int R> static hipError_t launch_R(const SweepArgs& a, hipStream_t st) {
-    const int lds = lds_total(R);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+template <int R, bool FAST> static hipError_t launch_RF(const SweepArgs& a, hipStream_t st) {
+    const int lds = lds_total<R>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sweep<R>, dim3(a.W), dim3(SW_TPB), lds, st, a);
+    hipLaunchKernelGGL((k_sweep<R, FAST>), dim3(a.W), dim3(SW_TPB), lds, st, a);
     return hipGetLastError();
+}
+template <int R> static hipError_t launch_R(const SweepArgs& a, hipStream_t st) {
+    return a.all_nomiss ? launch_RF<R, true>(a, st) : launch_RF<R, false>(a, st);
 }
 
 hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st) {
