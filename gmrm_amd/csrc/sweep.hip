@@ -318,8 +318,8 @@ struct Totals { double t0, t1, t2, t3; };
 
 template <int K>
 __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, int G, char* smem, const double* tab,
-                                                  const LaneIn (&lin)[2], const Totals (&tot)[2], double sigmae,
-                                                  double inv2sige, double nm1, const SampleOut out, bool writer) {
+                                                  const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
+                                                  double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer) {
     const int lane = threadIdx.x & 63;
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     double* s_val = reinterpret_cast<double*>(smem + L_VAL);
@@ -338,8 +338,12 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
         const int base = 64 * part;
         if (stopped || base >= nb) break;
         const int nbp = nb - base < 64 ? nb - base : 64;
-        const LaneIn in = part == 0 ? lin[0] : lin[1];
-        const Totals tt = part == 0 ? tot[0] : tot[1];
+        // field-wise selects between two register-resident sets (an indexed array would live in scratch)
+        LaneIn in;
+        in.m = part ? lin1.m : lin0.m; in.g = part ? lin1.g : lin0.g;
+        in.beta_old = part ? lin1.beta_old : lin0.beta_old; in.mave = part ? lin1.mave : lin0.mave; in.msig = part ? lin1.msig : lin0.msig;
+        Totals tt;
+        tt.t0 = part ? tot1.t0 : tot0.t0; tt.t1 = part ? tot1.t1 : tot0.t1; tt.t2 = part ? tot1.t2 : tot0.t2; tt.t3 = part ? tot1.t3 : tot0.t3;
         const bool act = lane < nbp;
         const int m = in.m, g = in.g;
         const double beta_old = in.beta_old;
@@ -431,9 +435,9 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
 // K = 4 (the reference's example mixtures) is inlined into the kernel; other K share out-of-line copies.
 template <int K>
 __device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, char* smem, const double* tab,
-                                          const LaneIn (&lin)[2], const Totals (&tot)[2], double sigmae,
-                                          double inv2sige, double nm1, const SampleOut out, bool writer) {
-    sample_batch_body<K>(nb, bmax_, nbf16, G, smem, tab, lin, tot, sigmae, inv2sige, nm1, out, writer);
+                                          const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
+                                          double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer) {
+    sample_batch_body<K>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tot0, tot1, sigmae, inv2sige, nm1, out, writer);
 }
 
 // Wavefront 0 fetches ALL totals of the generation with four 16-byte loads per lane (whole cache
@@ -441,7 +445,7 @@ __device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, c
 // polling), parks them in LDS and lane j picks the values of batch positions j and 64 + j.
 // Returns false on timeout.
 __device__ __forceinline__ bool poll_totals(int nb, bool fast, const unsigned long long* Ttg, unsigned tag, char* smem,
-                                            Totals (&tot)[2], unsigned* abort_word) {
+                                            Totals& tot0, Totals& tot1, unsigned* abort_word) {
     const int lane = threadIdx.x & 63;
     double* s_tot = reinterpret_cast<double*>(smem + L_TOT);
     const int nv = fast ? 2 * nb + 2 : 4 * nb;
@@ -469,7 +473,7 @@ __device__ __forceinline__ bool poll_totals(int nb, bool fast, const unsigned lo
     } else {
         if (lane < nb) t0 = Totals{s_tot[4 * lane], s_tot[4 * lane + 1], s_tot[4 * lane + 2], s_tot[4 * lane + 3]};
     }
-    tot[0] = t0; tot[1] = t1;
+    tot0 = t0; tot1 = t1;
     return !__any(bad);
 }
 
@@ -790,16 +794,18 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #endif
 
     // phase A for positions [b.p0, b.p0 + b.nb) (slices already in the ring) + publish
-    auto compute_publish = [&](Batch& b, LaneIn (&li)[2]) {
+    auto compute_publish = [&](Batch& b, LaneIn& li0, LaneIn& li1) {
         lds_barrier();                                // ring / plane / meta writes are visible (no vmcnt drain)
         const int nb = b.nb, p0 = b.p0;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            li[h] = LaneIn{0, 0, 0.0, 0.0, 1.0};
-            if (wave == 0 && lane + 64 * h < nb) {
-                const int sl = (p0 + lane + 64 * h) & (META_POS - 1);
-                li[h].m = mr_m[sl]; li[h].g = mr_g[sl]; li[h].beta_old = mr_beta[sl]; li[h].mave = mr_mave[sl]; li[h].msig = mr_msig[sl];
-            }
+        li0 = LaneIn{0, 0, 0.0, 0.0, 1.0};
+        li1 = LaneIn{0, 0, 0.0, 0.0, 1.0};
+        if (wave == 0 && lane < nb) {
+            const int sl = (p0 + lane) & (META_POS - 1);
+            li0.m = mr_m[sl]; li0.g = mr_g[sl]; li0.beta_old = mr_beta[sl]; li0.mave = mr_mave[sl]; li0.msig = mr_msig[sl];
+        }
+        if (wave == 0 && lane + 64 < nb) {
+            const int sl = (p0 + lane + 64) & (META_POS - 1);
+            li1.m = mr_m[sl]; li1.g = mr_g[sl]; li1.beta_old = mr_beta[sl]; li1.mave = mr_mave[sl]; li1.msig = mr_msig[sl];
         }
         max_nb = nb > max_nb ? nb : max_nb;
         // thread -> (marker mk of the batch, sub-slice sub): nbp = batch size rounded up to a power of two >= 16
@@ -906,9 +912,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     };
 
     Batch cur{0, 0, 0, 0u}, nxt{0, 0, 0, 0u}, tb{0, 0, 0, 0u};
-    LaneIn li_cur[2], li_nxt[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) li_cur[h] = li_nxt[h] = LaneIn{0, 0, 0.0, 0.0, 1.0};
+    LaneIn li_cur0{0, 0, 0.0, 0.0, 1.0}, li_cur1{0, 0, 0.0, 0.0, 1.0}, li_nxt0{0, 0, 0.0, 0.0, 1.0}, li_nxt1{0, 0, 0.0, 0.0, 1.0};
     bool bad = false;
     {
         const int first = RPOS < a.M ? RPOS : a.M;
@@ -945,7 +949,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (do_compute) {
             ensure(tb.p0 + tb.nb);
             ensure_meta(tb.p0 + tb.nb);
-            if (restart) compute_publish(tb, li_cur); else compute_publish(tb, li_nxt);
+            if (restart) compute_publish(tb, li_cur0, li_cur1); else compute_publish(tb, li_nxt0, li_nxt1);
         }
         if (restart) TRACE(1);
         PROF(1);   // dots + publish (restart: on the critical path; speculative: overlaps the exchange)
@@ -968,20 +972,27 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (wave == 0) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
-            Totals tot[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-            const bool okw = poll_totals(cur.nb, fast, Tb, cur.gen + 1u, smem, tot, abort_word);
+            Totals tot0{0.0, 0.0, 0.0, 0.0}, tot1{0.0, 0.0, 0.0, 0.0};
+            const bool okw = poll_totals(cur.nb, fast, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word);
             TRACE(3);
             PROF(4);   // wait for the totals
             bad |= !okw;
             if (okw) {
-                switch (K) {
-                    case 2: sample_batch<2>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 3: sample_batch<3>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 4: sample_batch_body<4>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 5: sample_batch<5>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 6: sample_batch<6>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    case 7: sample_batch<7>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                    default: sample_batch<8>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur, tot, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                if (K == 4) {
+                    sample_batch_body<4>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur0, li_cur1, tot0, tot1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0);
+                } else {
+                    // out-of-line copies take their inputs by address: hand them copies, so that the
+                    // loop-carried lane inputs themselves stay in registers (no scratch round trips)
+                    const LaneIn lc0 = li_cur0, lc1 = li_cur1;
+                    const Totals tc0 = tot0, tc1 = tot1;
+                    switch (K) {
+                        case 2: sample_batch<2>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                        case 3: sample_batch<3>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                        case 5: sample_batch<5>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                        case 6: sample_batch<6>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                        case 7: sample_batch<7>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                        default: sample_batch<8>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                    }
                 }
             }
         }
@@ -1020,7 +1031,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             restart = true;
         } else {                                      // promote: its partials are already at the reducers
             cur = nxt;
-            li_cur[0] = li_nxt[0]; li_cur[1] = li_nxt[1];
+            li_cur0 = li_nxt0; li_cur1 = li_nxt1;
             need_reduce = true;
         }
     }
