@@ -43,7 +43,7 @@ def build(force: bool = False, verbose: bool = False, prof: bool = False) -> Pat
     if prof:
         lib_prof = HERE / "libgmrm_hip_prof.so"
         saved = (LIB, FLAGS)
-        LIB, FLAGS = lib_prof, FLAGS + ["-DGM_SWEEP_PROF"]
+        LIB, FLAGS = lib_prof, FLAGS + ["-DGM_SWEEP_PROF"] + (["-DGM_PROF_TID=" + os.environ["GM_PROF_TID"]] if os.environ.get("GM_PROF_TID") else [])
         try:
             return _build(True, verbose, "_build_prof")
         finally:

@@ -38,7 +38,8 @@
 // of RPOS column slices in LDS (16-byte chunks XOR-swizzled by position so that 64 lanes reading
 // 64 different slices hit different banks).  Wavefronts 1-2 fetch the slices of upcoming positions
 // as coalesced 16-byte loads one round ahead, hold them in registers while the round runs and park
-// them in the ring once the sampled batch has released its slots (NA mask applied once, there).
+// them in the ring once the sampled batch has released its slots.  (Individuals without a phenotype
+// have residual 0, hence all-zero digit planes: phase A needs no mask; the update applies it.)
 // Wavefront 3 does the same for the per-marker inputs of the sampling step (marker id, group,
 // previous effect, mave, msig).
 //
@@ -492,7 +493,10 @@ template <> struct Slice<4> { using own_t = uint32_t; };
 #define TRACE(k) do { } while (0)
 #endif
 #ifdef GM_SWEEP_PROF
-#define PROF(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+#ifndef GM_PROF_TID
+#define GM_PROF_TID 0
+#endif
+#define PROF(i) do { if (tid == GM_PROF_TID) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
                                      prof[i] += t_ - tlast; tlast = t_; } } while (0)
 #else
 #define PROF(i) do { } while (0)
@@ -502,8 +506,7 @@ template <> struct Slice<4> { using own_t = uint32_t; };
 // Eight dot4 of one genotype byte's a-values (4 x int8) against the digit-plane record that lane
 // J of this 16-lane row holds (DPP row_newbcast).  All lanes of the row must be active.
 #define GM_DOT8(J, A4, ACC, PA, PB)                                                                   \
-    asm("s_nop 1\n\t"                                                                        \
-                 "v_dot4c_i32_i8_dpp %0, %8, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"  \
+    asm volatile("v_dot4c_i32_i8_dpp %0, %8, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"  \
                  "v_dot4c_i32_i8_dpp %1, %9, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"  \
                  "v_dot4c_i32_i8_dpp %2, %10, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
                  "v_dot4c_i32_i8_dpp %3, %11, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
@@ -513,7 +516,8 @@ template <> struct Slice<4> { using own_t = uint32_t; };
                  "v_dot4c_i32_i8_dpp %7, %15, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf"     \
                  : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]),                            \
                    "+v"(ACC[4]), "+v"(ACC[5]), "+v"(ACC[6]), "+v"(ACC[7])                             \
-                 : "v"(PA.x), "v"(PA.y), "v"(PA.z), "v"(PA.w), "v"(PB.x), "v"(PB.y), "v"(PB.z), "v"(PB.w), "v"(A4))
+                 : "v"(PA.x), "v"(PA.y), "v"(PA.z), "v"(PA.w), "v"(PB.x), "v"(PB.y), "v"(PB.z), "v"(PB.w), "v"(A4) \
+                 : "memory")   /* volatile + memory: the LDS reads written before a block stay before it */
 
 __device__ __forceinline__ uint32_t chunk_byte(const uint4& w, int j) {      // byte j (0..15) of a 16-byte chunk
     const uint32_t ww = j < 4 ? w.x : (j < 8 ? w.y : (j < 12 ? w.z : w.w));
@@ -629,27 +633,28 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     };
     refresh_planes();
 
+    // NA / out-of-range individuals: their residual is 0 and stays 0, so their digit planes are 0 and
+    // phase A may see ANY genotype code for them; only the residual update has to skip them.  The
+    // owner thread forces their codes to 01 (update value 0) when it reads its bytes in phase C.
+    own_t own_keep = 0, own_force = (own_t)0x55555555u;
+    if (valid) {
+        const own_t nam = *reinterpret_cast<const own_t*>(a.namask2 + b0);
+        own_keep = nam;
+        own_force = (own_t)(~nam) & (own_t)0x55555555u;
+    }
+
     // ---- loader role (wavefronts 1-3): one 16-byte chunk of PFN upcoming columns per round -----
-    // codes of NA / out-of-range individuals are forced to 01 (a = b = 0, update value 0)
     const bool loader = wave != 0;                    // wavefront 0 polls: its loads must not queue behind prefetches
     const int lt = loader ? tid - 64 : 0;
     const int lci = lt % CPP, lpj = lt / CPP;         // chunk of the slice, position within a load instruction
     const size_t cb_true = (size_t)wg * SB + (size_t)lci * 16;
     const bool lvalid = loader && cb_true < a.stride;
-    const size_t cb = lvalid ? cb_true : 0;           // out-of-range lanes read column bytes 0..15 and mask them away
-    uint4 lkeep = make_uint4(0u, 0u, 0u, 0u), lforce = make_uint4(0x55555555u, 0x55555555u, 0x55555555u, 0x55555555u);
-    if (lvalid) {
-        const uint4 nam = *reinterpret_cast<const uint4*>(a.namask2 + cb);
-        lkeep = nam;
-        lforce = make_uint4(~nam.x & 0x55555555u, ~nam.y & 0x55555555u, ~nam.z & 0x55555555u, ~nam.w & 0x55555555u);
-    }
-    auto masked = [&](const uint4& v) {
-        return make_uint4((v.x & lkeep.x) | lforce.x, (v.y & lkeep.y) | lforce.y, (v.z & lkeep.z) | lforce.z, (v.w & lkeep.w) | lforce.w);
-    };
+    const size_t cb = lvalid ? cb_true : 0;           // out-of-range lanes fetch column bytes 0..15 (in bounds, never used)
     auto ring_chunk = [&](int p, int chunk) -> uint4* {   // 16-byte chunk `chunk` of order position p
         return reinterpret_cast<uint4*>(ring + (size_t)((unsigned)p % (unsigned)RPOS) * SB + 16 * (chunk ^ (p & (CPP - 1))));
     };
-    uint4 pf[PFN];
+    u32x4 pf[PFN];                                    // in flight / parked in AGPRs (inline asm below owns them)
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;   // LDS byte offset of the ring
     int pos = 0;
     int hi = 0;                                       // ring holds order positions [pos, hi)
     int npf = 0;                                      // positions [hi, hi + npf) are in flight / in registers
@@ -660,7 +665,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #pragma unroll 1
             for (int p = from + lpj; p < to; p += PPI) {
                 const uint4 v = *reinterpret_cast<const uint4*>(a.bed + (size_t)a.order[p] * a.stride + cb);
-                *ring_chunk(p, lci) = masked(v);
+                *ring_chunk(p, lci) = v;
             }
         }
         __syncthreads();
@@ -687,12 +692,17 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     }
                 }
             }
+            // The column loads and their ring writes are inline asm on AGPR operands: the data never
+            // passes through compiler-managed registers (which would cost a wait per load), and the
+            // only wait is the explicit one in prefetch_commit, a whole sampling step later.
 #pragma unroll
             for (int c8 = 0; c8 < PFN; c8 += PFG) {
                 if (c8 * PPI < npf) {
 #pragma unroll
-                    for (int i = c8; i < c8 + PFG; i++)
-                        pf[i] = *reinterpret_cast<const uint4*>(a.bed + (size_t)idx[i] * a.stride + cb);
+                    for (int i = c8; i < c8 + PFG; i++) {
+                        const uint8_t* src = a.bed + (size_t)idx[i] * a.stride + cb;
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(pf[i]) : "v"(src) : "memory");
+                    }
                 }
             }
         }
@@ -705,13 +715,20 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (nc > npf) nc = npf;
         if (nc < 0) nc = 0;
         if (loader) {
+            if (nc > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // slot of this thread's first position; later ones are PPI apart (one conditional wrap each)
+            const int p_first = hi + lpj;
+            const int s_first = (int)((unsigned)p_first % (unsigned)RPOS);
 #pragma unroll
             for (int c8 = 0; c8 < PFN; c8 += PFG) {
                 if (c8 * PPI < nc) {
 #pragma unroll
                     for (int i = c8; i < c8 + PFG; i++) {
                         const int o = i * PPI + lpj;
-                        if (o < nc) *ring_chunk(hi + o, lci) = masked(pf[i]);
+                        int sl = s_first + i * PPI;
+                        sl = sl >= RPOS ? sl - RPOS : sl;
+                        const uint32_t dst = ring_lds + (uint32_t)sl * SB + 16u * (uint32_t)(lci ^ ((p_first + i * PPI) & (CPP - 1)));
+                        if (o < nc) asm volatile("ds_write_b128 %0, %1" : : "v"(dst), "a"(pf[i]) : "memory");
                     }
                 }
             }
@@ -845,6 +862,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             }
             w1 = chunk_at(c + 2);
 #define GM_STEP(J) { GM_DOT8(J, a4[J], acc, pa, pb); if (!FAST) { GM_DOT8(J, b4[J], bcc, pa, pb); } }
+            asm volatile("s_nop 1" ::: "memory");   // VALU write -> DPP read of the plane registers (rotation moves): 2 wait states
             GM_STEP(0) GM_STEP(1) GM_STEP(2) GM_STEP(3) GM_STEP(4) GM_STEP(5) GM_STEP(6) GM_STEP(7)
             GM_STEP(8) GM_STEP(9) GM_STEP(10) GM_STEP(11) GM_STEP(12) GM_STEP(13) GM_STEP(14) GM_STEP(15)
 #undef GM_STEP
@@ -1010,8 +1028,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             n_upd++;
             const int ps = pos + ctl[C_SUPD];
             const int ob = tid * R;                    // this thread's bytes of the slice
-            const uint32_t wd = *reinterpret_cast<const own_t*>(ring + (size_t)((unsigned)ps % (unsigned)RPOS) * SB +
-                                                                16 * ((ob >> 4) ^ (ps & (CPP - 1))) + (ob & 15));
+            const own_t raw = *reinterpret_cast<const own_t*>(ring + (size_t)((unsigned)ps % (unsigned)RPOS) * SB +
+                                                              16 * ((ob >> 4) ^ (ps & (CPP - 1))) + (ob & 15));
+            const uint32_t wd = (uint32_t)(own_t)((raw & own_keep) | own_force);
 #pragma unroll
             for (int i = 0; i < NI; i++) eps[i] += s_val[(wd >> (2 * i)) & 3u];
             refresh_planes();
@@ -1058,7 +1077,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
     }
 #ifdef GM_SWEEP_PROF
-    if (tid == 0 && (wg == 0 || wg == W / 2)) {
+    if (tid == GM_PROF_TID && (wg == 0 || wg == W / 2)) {
         for (int i = 0; i < 8; i++) a.stats[(wg == 0 ? 4 : 12) + i] = (long long)prof[i];
         if (wg != 0) for (int i = 0; i < 4; i++) a.stats[20 + i] = (long long)reinterpret_cast<unsigned long long*>(smem + L_M + 64)[i];
     }
