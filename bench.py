@@ -11,6 +11,8 @@ Markers are block-partitioned over the N GPUs (the reference's own rule, bayes.c
 total work is fixed, so scaling is "strong".  A step = one full Gibbs sweep (one iteration of
 Bayes::process: prologue draws, marker loop on every shard, residual exchange, hyper-parameter
 draws).  Genotypes, residual and all chain state are resident in HBM before the timed region.
+Defaults follow SURVEY.md 8(d): 2 warm-up sweeps (the chain starts from all-zero effects, so its
+first two sweeps update ~10x more markers than any later one), then 5 timed sweeps.
 
 The JSON line carries, besides the driver's contract fields:
   roofline     dominant kernel = the persistent sweep kernel; achieved = algorithmic bytes
@@ -44,8 +46,8 @@ CPU_THREADS = 1
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--markers", type=int, default=0, help="override the total marker count (debug)")
     ap.add_argument("--individuals", type=int, default=0, help="override N (debug)")
@@ -184,7 +186,7 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (it cannot
         # be read inside this process); the committed summary of the same workload is quoted.
         traffic = None
-        pmc = ROOT / "profiles" / "r01_v26_pmc_summary.json"
+        pmc = ROOT / "profiles" / "r01_v3_pmc_summary.json"
         if pmc.exists() and a.workload == "c3" and world == 1 and not a.markers and not a.individuals:
             try:
                 traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_k_sweep"]
@@ -206,12 +208,13 @@ def main():
                        "phenotype_na_rate": na_rate, "genotype_missing_rate": miss},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "bytes per launch: raw FETCH_SIZE + WRITE_SIZE from profiles/r01_v26_pmc_summary.json "
+                         "traffic_note": "bytes per launch: raw FETCH_SIZE + WRITE_SIZE from profiles/r01_v3_pmc_summary.json "
                                          "(separate rocprofv3 --pmc passes of this workload)" if traffic else None,
                          "kernel": "gm::k_sweep (persistent marker loop)",
                          "kernel_ms_avg": avg_kernel_s * 1e3,
                          "kernel_ms_per_launch": kern_ms, "kernel_ms_warmup_launches": warm_ms,
                          "kernel_ms_avg_all_launches": (sum(kern_ms) + sum(warm_ms)) / max(1, len(kern_ms) + len(warm_ms)),
+                         "kernel_ms_median": sorted(kern_ms)[len(kern_ms) // 2],
                          "algorithmic_bytes_per_launch": alg_bytes},
             "sweep": {"updates_per_sweep": upd, "sync_rounds_per_sweep": batches,
                       "update_fraction": [u / float(M) for u in upd]},

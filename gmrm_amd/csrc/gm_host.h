@@ -56,7 +56,7 @@ struct gmrm_ctx {
     std::vector<gm::Trait> tr;
     int num_cu = 0, R = 0, W = 0, Wpad = 0;
     bool concurrent = true, have_bed = false, have_groups = false;
-    int batch_init = 16, nb_factor16 = 16, spec_factor16 = 40;   // sweep schedule knobs (env GMRM_NB_FACTOR16 / GMRM_SPEC_FACTOR16)
+    int batch_init = 16, nb_factor16 = 24, spec_factor16 = 64;   // sweep schedule knobs (env GMRM_NB_FACTOR16 / GMRM_SPEC_FACTOR16)
 };
 
 namespace gm {

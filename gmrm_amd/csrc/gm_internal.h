@@ -9,9 +9,8 @@
 namespace gm {
 
 constexpr int SW_TPB  = 256;   // threads per workgroup of the sweep kernel (4 wavefronts)
-constexpr int SW_GB   = 8;     // markers accumulated per register group
-constexpr int SW_BMAX = 64;    // markers per batch <= lanes of the sampling wavefront
-constexpr int SW_VMAX = SW_BMAX * 4;   // exchanged values per batch (sa1,sa2,sb1,sb2 per marker)
+constexpr int SW_VMAX = 256;   // exchanged values per batch: 4 per marker (sa1,sa2,sb1,sb2; <= 64 markers) or
+                               // 2 per marker + 2 per batch in the no-missing-genotype layout (<= 120 markers)
 constexpr int KMAX = 8;
 constexpr int GMAX = 64;
 
@@ -45,8 +44,8 @@ struct SweepArgs {
     unsigned* cnt;                 // [96] arrival counters / abort word, zeroed per launch
     int batch_init;
     unsigned long long* trace;     // diagnostic build: [W][64][8] wall-clock stamps of rounds 2000..2063, or null
-    int nb_factor16;               // next batch = nb_factor16/16 x the run-length EMA (default 16 = 1x; measured best of 1..4x)
-    int spec_factor16;             // speculate when EMA >= spec_factor16/16 batches (default 40 = 2.5x)
+    int nb_factor16;               // next batch >= nb_factor16/16 x the run-length EMA, as a power of two (default 24 = 1.5x)
+    int spec_factor16;             // speculate when EMA >= spec_factor16/16 batches (default 64 = 4x: rarely pays)
     int all_nomiss;                // 1: no marker of this block has a missing genotype among the phenotyped individuals
 };
 
