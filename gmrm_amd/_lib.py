@@ -44,6 +44,11 @@ class HyperC(C.Structure):
                 ("n_updates", C.c_longlong), ("n_batches", C.c_longlong), ("sweep_device_ms", C.c_double)]
 
 
+class IngestStatsC(C.Structure):
+    _fields_ = [("bytes", C.c_size_t), ("seconds", C.c_double), ("read_seconds", C.c_double),
+                ("threads", C.c_int), ("chunk_bytes", C.c_size_t)]
+
+
 VP = C.c_void_p
 # name -> (restype, argtypes); every symbol include/gmrm_hip.h declares
 SIGNATURES = {
@@ -54,6 +59,7 @@ SIGNATURES = {
     "gmrm_ctx_destroy": (C.c_int, [VP]),
     "gmrm_ctx_sync": (C.c_int, [VP]),
     "gmrm_upload_bed": (C.c_int, [VP, c_u8_p, C.c_size_t, C.c_size_t]),
+    "gmrm_load_bed_file": (C.c_int, [VP, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(IngestStatsC)]),
     "gmrm_download_bed": (C.c_int, [VP, c_u8_p, C.c_size_t, C.c_size_t]),
     "gmrm_synth_bed": (C.c_int, [VP, C.c_uint64, C.c_double, C.c_double]),
     "gmrm_phen_prepare": (C.c_int, [c_double_p, c_u8_p, C.c_int, c_double_p, c_u8_p, c_int_p]),

@@ -96,6 +96,16 @@ class Context:
             raise ValueError(f"bed block must be [n_markers, {self.mbytes}] bytes")
         check(self.lib.gmrm_upload_bed(self.h, _bp(cols), int(first), int(cols.shape[0])))
 
+    def load_bed_file(self, path, file_first_marker=None, threads=8):
+        """Stream this context's marker block from a PLINK .bed file (validated magic + size) through
+        pinned buffers; returns a dict with bytes, seconds, GB/s."""
+        from ._lib import IngestStatsC
+        st = IngestStatsC()
+        first = self.S if file_first_marker is None else int(file_first_marker)
+        check(self.lib.gmrm_load_bed_file(self.h, str(path).encode(), first, int(threads), C.byref(st)))
+        return {"bytes": st.bytes, "seconds": st.seconds, "read_seconds": st.read_seconds, "threads": st.threads,
+                "chunk_bytes": st.chunk_bytes, "GBps": st.bytes / st.seconds / 1e9 if st.seconds > 0 else None}
+
     def download_bed(self, first=0, n=None):
         n = self.M - first if n is None else n
         out = np.empty((n, self.mbytes), dtype=np.uint8)

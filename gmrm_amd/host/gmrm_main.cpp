@@ -25,6 +25,7 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -198,30 +199,18 @@ int main(int argc, char** argv) {
     gmrm_ctx* ctx = nullptr;
     need(gmrm_ctx_create(&ctx, opt.device, N, Mt, Mt, 0, T), "gmrm_ctx_create");
 
-    // bayes.cpp:867-900: marker-major block after 3 magic bytes (checked here; upstream skips them unchecked)
+    // bayes.cpp:867-900: marker-major block after 3 magic bytes (validated by the library; upstream skips
+    // them unchecked).  Parallel chunked pread -> pinned ring -> copy engine, gmrm_amd/csrc/ingest.cpp.
     const size_t mbytes = ((size_t)N + 3) / 4;
     {
-        const double ts = now();
-        int fd = open(opt.bed_file.c_str(), O_RDONLY);
-        if (fd < 0) fatal("FATAL  : cannot open bed file " + opt.bed_file);
-        unsigned char magic[3];
-        if (pread(fd, magic, 3, 0) != 3 || magic[0] != 0x6c || magic[1] != 0x1b || magic[2] != 0x01)
-            fatal("FATAL  : " + opt.bed_file + " is not a SNP-major PLINK .bed file (magic bytes 6c 1b 01 expected).");
-        const size_t chunk_markers = std::max<size_t>(1, (size_t)(256u << 20) / mbytes);
-        std::vector<unsigned char> buf(chunk_markers * mbytes);
         printf("INFO   : rank %4d has allocated %zu bytes (%.3f GB) for raw data.\n", 0, (size_t)Mt * mbytes, double((size_t)Mt * mbytes) / 1.0E9);
-        for (size_t m0 = 0; m0 < (size_t)Mt; m0 += chunk_markers) {
-            const size_t nm = std::min(chunk_markers, (size_t)Mt - m0);
-            size_t got = 0;
-            while (got < nm * mbytes) {
-                ssize_t r = pread(fd, buf.data() + got, nm * mbytes - got, 3 + m0 * mbytes + got);
-                if (r <= 0) fatal("FATAL  : bed file shorter than the dim file says.");
-                got += (size_t)r;
-            }
-            need(gmrm_upload_bed(ctx, buf.data(), m0, nm), "gmrm_upload_bed");
-        }
-        close(fd);
-        printf("INFO   : time to load genotype data = %.2f seconds.\n", now() - ts);
+        gmrm_ingest_stats st;
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (gmrm_load_bed_file(ctx, opt.bed_file.c_str(), 0, (int)std::min(16u, std::max(1u, hw)), &st) != GMRM_OK)
+            fatal(std::string("FATAL  : ") + gmrm_last_error());
+        printf("INFO   : time to load genotype data = %.2f seconds.\n", st.seconds);
+        printf("INFO   : genotype ingest %.3f GB at %.2f GB/s (%d reader threads, %.2f s inside pread).\n",
+               double(st.bytes) / 1.0E9, st.seconds > 0 ? double(st.bytes) / st.seconds / 1.0E9 : 0.0, st.threads, st.read_seconds);
     }
 
     // phenotype.cpp:587-673

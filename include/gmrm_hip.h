@@ -61,6 +61,22 @@ int gmrm_ctx_sync(gmrm_ctx* ctx);                      /* wait for every stream 
 /* Genotypes: Bayes::load_genotype (src/bayes.cpp:867-900).  `cols` is marker-major,
  * ceil(N/4) bytes per marker, PLINK 2-bit codes LSB first (no 3-byte magic). */
 int gmrm_upload_bed(gmrm_ctx* ctx, const uint8_t* cols, size_t first_marker, size_t n_markers);
+
+/* .bed ingest at scale: the whole of Bayes::load_genotype
+ * (src/bayes.cpp:867-900, chunked MPI_File_read_at of src/utilities.hpp:28-53) for this context's
+ * marker block, straight from the file: markers [file_first_marker, file_first_marker + M) of the
+ * PLINK .bed at `path` go to device markers [0, M).  The 3 magic bytes and the file size are
+ * checked (the reference checks neither).  `nthreads` reader threads (1..64) fill pinned buffers
+ * with parallel pread()s while the previous chunk is copied.  `stats` may be NULL. */
+typedef struct gmrm_ingest_stats {
+    size_t bytes;          /* genotype bytes moved */
+    double seconds;        /* wall time of the call */
+    double read_seconds;   /* part of it spent inside pread() (not overlapped with the copies) */
+    int threads;
+    size_t chunk_bytes;
+} gmrm_ingest_stats;
+int gmrm_load_bed_file(gmrm_ctx* ctx, const char* path, size_t file_first_marker, int nthreads,
+                       gmrm_ingest_stats* stats);
 int gmrm_download_bed(gmrm_ctx* ctx, uint8_t* cols, size_t first_marker, size_t n_markers);
 /* Synthetic genotypes generated on the device, keyed by (seed, global marker, individual):
  * copies of A1 ~ Binomial(2, maf) (example/data_sim.R:15), code 01 with prob. miss_rate. */
