@@ -106,6 +106,25 @@ class Context:
         return {"bytes": st.bytes, "seconds": st.seconds, "read_seconds": st.read_seconds, "threads": st.threads,
                 "chunk_bytes": st.chunk_bytes, "GBps": st.bytes / st.seconds / 1e9 if st.seconds > 0 else None}
 
+    # ---- Bayes::predict building blocks (src/bayes.cpp:16-284) ----
+    def predict_g(self, t, beta_local):
+        beta_local = np.ascontiguousarray(beta_local, dtype=np.float64)
+        if beta_local.shape != (self.M,):
+            raise ValueError("beta_local must hold one value per local marker")
+        g = np.empty(self.N, dtype=np.float64)
+        check(self.lib.gmrm_predict_g(self.h, int(t), _dp(beta_local), _dp(g)))
+        return g
+
+    def assoc(self, t, yk=None):
+        xtx = np.empty(self.M, dtype=np.float64)
+        xty = np.empty(self.M, dtype=np.float64)
+        if yk is not None:
+            yk = np.ascontiguousarray(yk, dtype=np.float64)
+            if yk.shape != (self.N,):
+                raise ValueError("yk must hold one value per individual")
+        check(self.lib.gmrm_assoc(self.h, int(t), _dp(yk) if yk is not None else None, _dp(xtx), _dp(xty)))
+        return xtx, xty
+
     def download_bed(self, first=0, n=None):
         n = self.M - first if n is None else n
         out = np.empty((n, self.mbytes), dtype=np.uint8)

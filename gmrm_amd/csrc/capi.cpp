@@ -7,6 +7,7 @@
 #include "gm_host.h"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -367,6 +368,64 @@ int gmrm_eps_sigma(gmrm_ctx* c, int t, double* sigmae) {
     if (int r = sumsq_common(c, t, true, 4 * c->mbytes, &s, nullptr)) return r;  // phenotype.cpp:453-457
     *sigmae = s / (double)c->tr[t].nonas * 0.5;
     return GMRM_OK;
+}
+
+// ---- Bayes::predict building blocks (src/bayes.cpp:16-284) -------------------------------------
+int gmrm_predict_g(gmrm_ctx* c, int t, const double* beta_local, double* g) {
+    if (int r = need_trait(c, t, true)) return r;
+    if (!beta_local || !g) return fail(GMRM_EINVAL, "null argument");
+    Trait& tr = c->tr[t];
+    if (!tr.have_stats) return fail(GMRM_ESTATE, "marker statistics not computed (gmrm_marker_stats)");
+    HIPCHK(hipSetDevice(c->device));
+    double *d_beta = nullptr, *d_g = nullptr;
+    int rc = GMRM_OK;
+    hipError_t e;
+    if ((e = dalloc(&d_beta, (size_t)std::max(1, c->M))) != hipSuccess) return hip_fail(e, "hipMalloc");
+    if ((e = dalloc(&d_g, 4 * c->stride)) != hipSuccess) { (void)hipFree(d_beta); return hip_fail(e, "hipMalloc"); }
+    do {
+        if ((e = hipMemset(d_g, 0, 4 * c->stride * sizeof(double))) != hipSuccess) break;
+        if ((e = hipMemcpy(d_beta, beta_local, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
+        if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+        if ((e = launch_predict_g(c->bed, tr.namask2, c->stride, c->M, tr.mave, tr.msig, d_beta, d_g, tr.stream)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(tr.stream)) != hipSuccess) break;
+        e = hipMemcpy(g, d_g, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost);
+    } while (0);
+    if (e != hipSuccess) rc = hip_fail(e, "gmrm_predict_g");
+    (void)hipFree(d_beta); (void)hipFree(d_g);
+    return rc;
+}
+
+int gmrm_assoc(gmrm_ctx* c, int t, const double* yk, double* xtx, double* xty) {
+    if (int r = need_trait(c, t, true)) return r;
+    if (!xtx || !xty) return fail(GMRM_EINVAL, "null argument");
+    Trait& tr = c->tr[t];
+    HIPCHK(hipSetDevice(c->device));
+    double *d_y = nullptr, *d_xx = nullptr, *d_xy = nullptr;
+    int rc = GMRM_OK;
+    hipError_t e = hipSuccess;
+    do {
+        if ((e = dalloc(&d_xx, (size_t)std::max(1, c->M))) != hipSuccess) break;
+        if ((e = dalloc(&d_xy, (size_t)std::max(1, c->M))) != hipSuccess) break;
+        const double* ysrc = tr.eps;                                   // default: the residual as it stands
+        if (yk) {
+            if ((e = dalloc(&d_y, 4 * c->stride)) != hipSuccess) break;
+            if ((e = hipMemset(d_y, 0, 4 * c->stride * sizeof(double))) != hipSuccess) break;
+            if ((e = hipMemcpy(d_y, yk, (size_t)c->N * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
+            ysrc = d_y;
+        }
+        if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+        if ((e = launch_assoc(c->bed, tr.namask2, c->stride, c->M, ysrc, d_xx, d_xy, tr.stream)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(tr.stream)) != hipSuccess) break;
+        if (c->M > 0) {
+            if ((e = hipMemcpy(xtx, d_xx, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) break;
+            e = hipMemcpy(xty, d_xy, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost);
+        }
+    } while (0);
+    if (e != hipSuccess) rc = hip_fail(e, "gmrm_assoc");
+    if (d_y) (void)hipFree(d_y);
+    if (d_xx) (void)hipFree(d_xx);
+    if (d_xy) (void)hipFree(d_xy);
+    return rc;
 }
 
 int gmrm_set_groups(gmrm_ctx* c, const int* group_local) {

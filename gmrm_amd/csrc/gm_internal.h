@@ -66,6 +66,10 @@ hipError_t launch_marker_stats(const uint8_t* bed, const uint8_t* namask2, size_
                                double* mave, double* msig, uint8_t* nomiss, hipStream_t st);
 hipError_t launch_synth(uint8_t* bed, size_t stride, int N, int M, int S, uint64_t seed,
                         double maf, double miss, hipStream_t st);
+hipError_t launch_predict_g(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* mave,
+                            const double* msig, const double* beta, double* g, hipStream_t st);
+hipError_t launch_assoc(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* y,
+                        double* xtx, double* xty, hipStream_t st);
 hipError_t launch_selftest(int op, const double* x, double* y, int n, hipStream_t st);
 hipError_t launch_delta_export(const double* eps, const double* start, double* q, size_t n4, hipStream_t st);
 hipError_t launch_delta_import(double* eps, const double* start, const double* q, size_t n4, hipStream_t st);

@@ -302,6 +302,99 @@ struct DevMt {                                        // a plain mt19937 in regi
         return mt_temper(mt[idx++]);
     }
 };
+// ---- Bayes::predict (src/bayes.cpp:16-284), SURVEY section 8f-3 ---------------------------------
+// g_i = sum over this block's markers, in marker order, of ((a - mave) * b * na * msig) * beta_m
+// (bayes.cpp:113-122; the "transposed" use of the genotype table).  Thread = 8 individuals kept in
+// registers for the whole pass; markers with a zero mean effect add +-0 and are skipped.
+__global__ __launch_bounds__(256) void k_predict_g(const uint8_t* __restrict__ bed, const uint8_t* __restrict__ namask2,
+                                                   size_t stride, int M, const double* __restrict__ mave,
+                                                   const double* __restrict__ msig, const double* __restrict__ beta,
+                                                   double* __restrict__ g) {
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;          // 2-byte word of every column (8 individuals)
+    if (w * 2 >= stride) return;
+    const uint32_t nam = reinterpret_cast<const uint16_t*>(namask2)[w];
+    const uint32_t keep = nam, force = ~nam & 0x5555u;
+    double acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = 0.0;
+    constexpr int U = 32;                                           // column words in flight per thread (HBM latency)
+    for (int m0 = 0; m0 < M; m0 += U) {
+        uint32_t wd[U];
+        double bm[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int m = m0 + u < M ? m0 + u : M - 1;
+            bm[u] = m0 + u < M ? beta[m] : 0.0;
+            wd[u] = reinterpret_cast<const uint16_t*>(bed + (size_t)m * stride)[w];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (bm[u] != 0.0) {                                      // wave-uniform
+                const int m = m0 + u;
+                const double av = mave[m], sg = msig[m];
+                double tv[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) tv[c] = (((code_a(c) - av) * code_b(c)) * sg) * bm[u];
+                const uint32_t x = (wd[u] & keep) | force;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t c = (x >> (2 * i)) & 3u;
+                    acc[i] += c == 0 ? tv[0] : (c == 1 ? tv[1] : (c == 2 ? tv[2] : tv[3]));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) g[8 * w + i] = acc[i];
+}
+
+// Per marker: xtx = sum (a*b*na)^2 (an integer: #(a=1) + 4 #(a=2)), xty = sum a*b*na*y_i
+// (bayes.cpp:188-196).  One wavefront per AB consecutive markers: a y word (16 doubles, served from
+// L2) is loaded once and used for all of them, so the L2 traffic is 8N/AB bytes per marker.
+constexpr int AB = 8;
+__global__ __launch_bounds__(256) void k_assoc(const uint8_t* __restrict__ bed, const uint8_t* __restrict__ namask2,
+                                               size_t stride, int M, const double* __restrict__ y,
+                                               double* __restrict__ xtx, double* __restrict__ xty) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m0 = (blockIdx.x * 4 + wave) * AB;
+    if (m0 >= M) return;
+    const uint32_t* msk = reinterpret_cast<const uint32_t*>(namask2);
+    const size_t nw = stride / 4;
+    int n1[AB], n2[AB];
+    double s[AB];
+#pragma unroll
+    for (int k = 0; k < AB; k++) { n1[k] = 0; n2[k] = 0; s[k] = 0.0; }
+    for (size_t w = lane; w < nw; w += 64) {
+        const uint32_t nam = msk[w];
+        uint32_t x[AB];
+#pragma unroll
+        for (int k = 0; k < AB; k++) {
+            const int m = m0 + k < M ? m0 + k : M - 1;
+            x[k] = (reinterpret_cast<const uint32_t*>(bed + (size_t)m * stride)[w] & nam) | (~nam & 0x55555555u);
+        }
+        double yw[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) yw[i] = y[16 * w + i];
+#pragma unroll
+        for (int k = 0; k < AB; k++) {
+            const uint32_t lo = x[k] & 0x55555555u, hi = (x[k] >> 1) & 0x55555555u;
+            n2[k] += __popc(~lo & ~hi & 0x55555555u);               // code 00: a = 2
+            n1[k] += __popc(~lo & hi);                               // code 10: a = 1
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t c = (x[k] >> (2 * i)) & 3u;
+                s[k] += (c == 0 ? 2.0 : (c == 2 ? 1.0 : 0.0)) * yw[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < AB; k++) {
+        const int a1 = wave_sum_i(n1[k]), a2 = wave_sum_i(n2[k]);
+        const double t = wave_sum(s[k]);
+        if (lane == 0 && m0 + k < M) { xtx[m0 + k] = (double)((long long)a1 + 4ll * a2); xty[m0 + k] = t; }
+    }
+}
+
 __global__ void k_selftest(int op, const double* __restrict__ x, double* __restrict__ y, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (op == 3) {
@@ -320,6 +413,20 @@ __global__ void k_selftest(int op, const double* __restrict__ x, double* __restr
 }
 hipError_t launch_selftest(int op, const double* x, double* y, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, st, op, x, y, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_predict_g(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* mave,
+                            const double* msig, const double* beta, double* g, hipStream_t st) {
+    const size_t words = stride / 2;
+    if (words == 0 || M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_predict_g, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, bed, namask2, stride, M, mave, msig, beta, g);
+    return hipGetLastError();
+}
+hipError_t launch_assoc(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* y,
+                        double* xtx, double* xty, hipStream_t st) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_assoc, dim3((M + 4 * AB - 1) / (4 * AB)), dim3(256), 0, st, bed, namask2, stride, M, y, xtx, xty);
     return hipGetLastError();
 }
 

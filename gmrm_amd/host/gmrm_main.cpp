@@ -18,6 +18,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +27,7 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -126,8 +128,10 @@ Opts parse(int argc, char** argv) {
         fatal("FATAL  : you need to activate BOTH --group-index-file and --group-mixture-file");
     if (o.mimic_hydra && o.phen_files.size() > 1)
         fatal("FATAL  : with --mimic-hydra, only a single phenotype can be processed.");
-    if (o.predict)
-        fatal("FATAL  : --predict (posterior-mean association statistics) is not part of this build: it covers the sampling hot path only.");
+    if (o.predict) {                                                       // options.cpp:205-214
+        if (o.bim_file.empty()) fatal("FATAL  : you need to pass a bim file with --bim-file when activating --predict");
+        if (o.ref_bim_file.empty()) fatal("FATAL  : you need to pass a reference bim file with --ref-bim-file when activating --predict");
+    }
     return o;
 }
 
@@ -169,6 +173,112 @@ struct HistFile {                 // xfiles.hpp:14-38 via POSIX pwrite
     }
 };
 
+// fs::path::replace_extension on the file-name part of p
+std::string replace_ext(const std::string& p, const std::string& ext) {
+    const size_t slash = p.find_last_of('/');
+    const size_t name0 = slash == std::string::npos ? 0 : slash + 1;
+    const size_t dot = p.find_last_of('.');
+    if (dot != std::string::npos && dot > name0) return p.substr(0, dot) + ext;
+    return p + ext;
+}
+
+// Bayes::cross_bim_files (bayes.cpp:289-316): row number = marker index
+void cross_bim_files(const Opts& opt, std::vector<std::string>& rsid, std::unordered_map<std::string, int>& refrsid) {
+    printf("INFO   : bim file:     %s\n", opt.bim_file.c_str());
+    printf("INFO   : ref bim file: %s\n", opt.ref_bim_file.c_str());
+    std::ifstream in(opt.bim_file);
+    if (!in) fatal("Error: can not open the file [" + opt.bim_file + "] to read.");
+    std::string id, a1, a2;
+    unsigned chr, pos;
+    float gpos;
+    while (in >> chr >> id >> gpos >> pos >> a1 >> a2) rsid.push_back(id);
+    printf("INFO   : found %d ids in bim file\n", (int)rsid.size());
+    std::ifstream refin(opt.ref_bim_file);
+    if (!refin) fatal("Error: can not open the file [" + opt.ref_bim_file + "] to read.");
+    int idx = 0;
+    while (refin >> chr >> id >> gpos >> pos >> a1 >> a2) refrsid[id] = idx++;
+    printf("INFO   : found %d ids in reference bim file\n", idx);
+}
+
+// Bayes::predict (bayes.cpp:16-284) on one GPU = one rank: posterior-mean effects from <stem>.bet,
+// g = Z beta (k_predict_g), leave-other-ranks-out correction of y (nothing to leave out with one
+// rank, bayes.cpp:141-142), per-marker OLS beta / t / se / p (k_assoc + host arithmetic), <stem>.mlma.
+void run_predict(const Opts& opt, gmrm_ctx* ctx, int N, int M, const std::vector<std::string>& stems,
+                 const std::vector<std::vector<double>>& eps0, const std::vector<int>& nonas) {
+    const double ts = now();
+    std::vector<std::string> rsid;
+    std::unordered_map<std::string, int> refrsid;
+    cross_bim_files(opt, rsid, refrsid);
+    if ((int)rsid.size() < M) fatal("FATAL  : bim file has fewer rows than markers in the dim file.");
+    const int T = (int)stems.size();
+    for (int t = 0; t < T; t++) {
+        need(gmrm_marker_stats(ctx, t), "gmrm_marker_stats");
+        const std::string base = opt.out_dir.empty() ? stems[t] : opt.out_dir + "/" + stems[t];
+        const std::string inbet = replace_ext(base, ".bet"), outmlma = base + ".mlma";   // phenotype.cpp:115-127
+        unlink(outmlma.c_str());                                                         // bayes.cpp:33
+        const int fb = open(inbet.c_str(), O_RDONLY);
+        if (fb < 0) fatal("FATAL  : cannot open " + inbet);
+        HistFile fm;
+        fm.open_fresh(outmlma);
+        struct stat sb;
+        fstat(fb, &sb);
+        unsigned Mtot_ = 0;
+        if (pread(fb, &Mtot_, 4, 0) != 4) fatal("FATAL  : " + inbet + " is empty");
+        if (Mtot_ != refrsid.size()) {                                                   // bayes.cpp:48-51
+            printf("Mismatch between expected and Mtot read from .bet file: %lu vs %d\n", (unsigned long)rsid.size(), Mtot_);
+            std::exit(1);
+        }
+        const size_t rec = (size_t)Mtot_ * 8 + 4;
+        if (((size_t)sb.st_size - 4) % rec != 0) fatal("FATAL  : " + inbet + " is truncated (size is not 4 + k * (4 + 8 * Mtot)).");
+        const unsigned niter = (unsigned)(((size_t)sb.st_size - 4) / rec);
+        printf("INFO   : Number of recorded iterations in .bet file %d: %u\n", t, niter);
+        std::vector<double> beta_sum(Mtot_, 0.0), beta_it(Mtot_);
+        for (unsigned i = 0; i < niter; i++) {                                           // bayes.cpp:68-76
+            const off_t off = 4 + (off_t)rec * i + 4;
+            if (pread(fb, beta_it.data(), (size_t)Mtot_ * 8, off) != (ssize_t)((size_t)Mtot_ * 8)) fatal("FATAL  : short read on " + inbet);
+            for (unsigned j = 0; j < Mtot_; j++) beta_sum[j] += beta_it[j];
+        }
+        for (unsigned j = 0; j < Mtot_; j++) beta_sum[j] /= double(niter);
+        close(fb);
+
+        // bayes.cpp:93-122.  beta_sum is indexed by the row of the CURRENT bim (mglo), as upstream does.
+        std::vector<double> beta_local(M, 0.0);
+        std::vector<int> rm(M, -1);
+        for (int m = 0; m < M; m++) {
+            auto f = refrsid.find(rsid[m]);
+            if (f == refrsid.end()) continue;
+            rm[m] = f->second;
+            if ((unsigned)m >= Mtot_) fatal("FATAL  : marker row beyond the .bet file's Mtot (upstream reads out of bounds here).");
+            beta_local[m] = beta_sum[m];
+        }
+        std::vector<double> g_k(N), y_k(eps0[t].begin(), eps0[t].begin() + N);
+        need(gmrm_predict_g(ctx, t, beta_local.data(), g_k.data()), "gmrm_predict_g");
+        const std::vector<double>& g = g_k;                                              // MPI_Allreduce over one rank
+        for (int i = 0; i < N; i++) y_k[i] -= (g[i] - g_k[i]);                           // bayes.cpp:141-142
+        double sigma = 0.0;
+        for (int i = 0; i < N; i++) sigma += y_k[i] * y_k[i];
+        sigma /= nonas[t];
+        std::vector<double> xtx(M), xty(M);
+        need(gmrm_assoc(ctx, t, y_k.data(), xtx.data(), xty.data()), "gmrm_assoc");
+        const int LLEN = 123 + 1;
+        std::vector<char> todump((size_t)LLEN * (size_t)std::max(1, M));
+        int n_rem = 0;
+        for (int m = 0; m < M; m++) {
+            if (rm[m] < 0) { printf("WARNING: marker id %s excluded -- no match\n", rsid[m].c_str()); n_rem++; continue; }
+            const double beta = xty[m] / xtx[m];                                         // bayes.cpp:198-205
+            const double tdist = xty[m] / sqrt(sigma * xtx[m]);
+            const double se = beta / tdist;
+            const double pval = 1.0 - erf(sqrt(tdist * tdist * 0.5));                   // 1 - gamma_p(1/2, t^2/2)
+            const int cx = snprintf(&todump[(size_t)(m - n_rem) * (LLEN - 1)], LLEN, "%20s %8d %8d %20.15f %20.15f %20.15f %20.15f\n",
+                                    rsid[m].c_str(), m, rm[m], beta, tdist, se, pval);
+            if (cx < 0 || cx >= LLEN) fatal("FATAL  : .mlma record longer than 123 bytes (marker id over 20 characters or a value over 4 integer digits).");   // bayes.cpp:235 assert
+        }
+        if (M - n_rem > 0) fm.put(todump.data(), (size_t)(LLEN - 1) * (size_t)(M - n_rem), 0);
+        close(fm.fd);
+    }
+    printf("INFO   : Time to compute the predictions: %.2f seconds.\n", now() - ts);
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -187,11 +297,13 @@ int main(int argc, char** argv) {
         Mt = atoi(tok[1].c_str());
         if (opt.truncm > 0 && opt.truncm < (unsigned)Mt) Mt = (int)opt.truncm;
     }
-    if (opt.group_mixture_file.empty())
-        fatal("FATAL  : can not open the mixture file . Use the --group-mixture-file option!");   // options.cpp:259-261
     std::vector<double> cva;
     int G = 0, K = 0;
-    read_mixtures(opt.group_mixture_file, cva, G, K);
+    if (!opt.predict) {                                                      // options.hpp:12-13
+        if (opt.group_mixture_file.empty())
+            fatal("FATAL  : can not open the mixture file . Use the --group-mixture-file option!");   // options.cpp:259-261
+        read_mixtures(opt.group_mixture_file, cva, G, K);
+    }
 
     if (gmrm_device_count() < 1) fatal("FATAL  : no HIP device visible; this build has no CPU path.");
     const int T = (int)opt.phen_files.size();
@@ -215,6 +327,8 @@ int main(int argc, char** argv) {
 
     // phenotype.cpp:587-673
     std::vector<std::string> stems;
+    std::vector<std::vector<double>> eps0;                                   // predict: the centred, scaled phenotypes
+    std::vector<int> nonas_t;
     for (int t = 0; t < T; t++) {
         std::ifstream f(opt.phen_files[t]);
         if (!f.is_open()) fatal("FATAL: could not open phenotype file: " + opt.phen_files[t]);
@@ -239,8 +353,16 @@ int main(int argc, char** argv) {
         need(gmrm_upload_trait(ctx, t, eps.data(), mask4.data(), nonas), "gmrm_upload_trait");
         printf("INFO   : %s has %d NAs and %d non-NAs.\n", opt.phen_files[t].c_str(), N - nonas, nonas);
         stems.push_back(stem_of(opt.phen_files[t]));
+        if (opt.predict) { eps0.push_back(eps); nonas_t.push_back(nonas); }
     }
     printf("INFO   : output directory: %s\n", opt.out_dir.c_str());
+    if (opt.predict) {                                                       // main.cpp:15-16, bayes.cpp:794
+        const double ts = now();
+        run_predict(opt, ctx, N, Mt, stems, eps0, nonas_t);
+        (void)ts;
+        gmrm_ctx_destroy(ctx);
+        return 0;
+    }
 
     // bayes.cpp:830-853 (only column 2 is used; the upstream check is `group > G`, off by one)
     std::vector<int> group_index;

@@ -113,6 +113,16 @@ int gmrm_sumsqr(gmrm_ctx* ctx, int t, double* out);
  * *sigmae receives the value set_sigmae() would. */
 int gmrm_eps_sigma(gmrm_ctx* ctx, int t, double* sigmae);
 
+/* Bayes::predict building blocks (src/bayes.cpp:16-284).
+ * gmrm_predict_g: g_i = sum over this context's markers, in marker order, of
+ *   ((a - mave) * b * na * msig) * beta_local[m]          (bayes.cpp:93-122, g_k)
+ *   beta_local: M posterior-mean effects of this block (host), g: N doubles (host, out).
+ * gmrm_assoc: per marker xtx = sum (a*b*na)^2, xty = sum a*b*na*yk_i   (bayes.cpp:172-196)
+ *   yk: N doubles (host; NULL = the phenotype's residual as it stands), xtx/xty: M doubles (host, out).
+ * Both need gmrm_upload_trait + gmrm_marker_stats for phenotype t. */
+int gmrm_predict_g(gmrm_ctx* ctx, int t, const double* beta_local, double* g);
+int gmrm_assoc(gmrm_ctx* ctx, int t, const double* yk, double* xtx, double* xty);
+
 /* ------------------------------------------------------------------------------------
  * Fused marker loop: the body of `for (mrki...)` in Bayes::process for this context's
  * markers and phenotype t (src/bayes.cpp:375-553 -> dot_product, Gibbs step 396-492,

@@ -813,3 +813,58 @@ int orc_csv_line(char* buf, size_t len, unsigned it, const double* sigmag, int G
     n += (size_t)snprintf(buf + n, len - n, "\n");
     return (int)n;
 }
+
+/* ---- Bayes::predict (bayes.cpp:16-284), restated; SURVEY section 8f-3 ----------------------------
+ * Pinning: the genotype / NA tables are pinned (ref_luts.bin); the p-value uses
+ * boost::math::gamma_p(0.5, x) upstream (bayes.cpp:205) -- Boost is absent here, so it is restated
+ * as erf(sqrt(x)) (the same function; PARITY UNPINNED at the last digits of the p-value). */
+
+/* bayes.cpp:93-122: g_k over markers [0, M) of a block in marker order (the reference's OpenMP
+ * loop adds in an unspecified order; this is its one-thread order) */
+void orc_predict_g(const uint8_t* bed, int M, int mbytes, const uint8_t* mask4, int im4,
+                   const double* mave, const double* msig, const double* beta, double* g_k) {
+    build_luts();
+    for (int i = 0; i < im4 * 4; i++) g_k[i] = 0.0;
+    for (int mrki = 0; mrki < M; mrki++) {
+        const uint8_t* bedm = bed + (size_t)mrki * (size_t)mbytes;
+        for (int j = 0; j < im4; j++)
+            for (int k = 0; k < 4; k++) {
+                const double val = (g_lut_a[bedm[j] * 4 + k] - mave[mrki]) * g_lut_b[bedm[j] * 4 + k] * g_lut_na[mask4[j] * 4 + k] * msig[mrki];
+                g_k[j * 4 + k] += val * beta[mrki];
+            }
+    }
+}
+
+/* bayes.cpp:172-196: xtx, xty of every marker of the block */
+void orc_assoc(const uint8_t* bed, int M, int mbytes, const uint8_t* mask4, int im4, const double* y_k,
+               double* xtx_out, double* xty_out) {
+    build_luts();
+#ifdef _OPENMP
+#pragma omp parallel for
+#endif
+    for (int mrki = 0; mrki < M; mrki++) {
+        const uint8_t* bedm = bed + (size_t)mrki * (size_t)mbytes;
+        double xtx = 0.0, xty = 0.0;
+        for (int j = 0; j < im4; j++)
+            for (int k = 0; k < 4; k++) {
+                const double val = g_lut_a[bedm[j] * 4 + k] * g_lut_b[bedm[j] * 4 + k] * g_lut_na[mask4[j] * 4 + k];
+                xtx += val * val;
+                xty += val * y_k[j * 4 + k];
+            }
+        xtx_out[mrki] = xtx;
+        xty_out[mrki] = xty;
+    }
+}
+
+/* bayes.cpp:198-205: beta, tdist, se, pval from xtx, xty, sigma */
+void orc_mlma_stats(double xtx, double xty, double sigma, double* beta, double* tdist, double* se, double* pval) {
+    *beta = xty / xtx;
+    *tdist = xty / sqrt(sigma * xtx);
+    *se = *beta / *tdist;
+    *pval = 1.0 - erf(sqrt(*tdist * *tdist * 0.5));        /* 1 - gamma_p(1/2, t^2/2) */
+}
+
+/* bayes.cpp:233-234: one .mlma record (123 bytes for ids of <= 20 characters) */
+int orc_mlma_line(char* buf, size_t len, const char* id, int mglo, int rmglo, double beta, double tdist, double se, double pval) {
+    return snprintf(buf, len, "%20s %8d %8d %20.15f %20.15f %20.15f %20.15f\n", id, mglo, rmglo, beta, tdist, se, pval);
+}

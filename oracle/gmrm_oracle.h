@@ -127,6 +127,15 @@ orc_rng* orc_chain_rng_m(orc_chain* c);
 int orc_csv_line(char* buf, size_t len, unsigned it, const double* sigmag, int G,
                  double sigmae, int m0_sum, const double* pi_est, int K);
 
+
+/* Bayes::predict (bayes.cpp:16-284) */
+void orc_predict_g(const uint8_t* bed, int M, int mbytes, const uint8_t* mask4, int im4,
+                   const double* mave, const double* msig, const double* beta, double* g_k);
+void orc_assoc(const uint8_t* bed, int M, int mbytes, const uint8_t* mask4, int im4, const double* y_k,
+               double* xtx_out, double* xty_out);
+void orc_mlma_stats(double xtx, double xty, double sigma, double* beta, double* tdist, double* se, double* pval);
+int  orc_mlma_line(char* buf, size_t len, const char* id, int mglo, int rmglo, double beta, double tdist, double se, double pval);
+
 #ifdef __cplusplus
 }
 #endif

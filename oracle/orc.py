@@ -105,6 +105,11 @@ _SIGS = {
     "orc_chain_rng_m": (C.POINTER(OrcRng), [C.c_void_p]),
     "orc_csv_line": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint, c_double_p, C.c_int, C.c_double, C.c_int,
                                c_double_p, C.c_int]),
+    "orc_predict_g": (None, [c_u8_p, C.c_int, C.c_int, c_u8_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "orc_assoc": (None, [c_u8_p, C.c_int, C.c_int, c_u8_p, C.c_int, c_double_p, c_double_p, c_double_p]),
+    "orc_mlma_stats": (None, [C.c_double, C.c_double, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p]),
+    "orc_mlma_line": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                C.c_double, C.c_double]),
 }
 
 _libs = {}
@@ -223,3 +228,38 @@ def ns_iterate(chains, it):
     """The build's sweep-synchronous multi-rank schedule (orc_ns_iterate)."""
     arr = (C.c_void_p * len(chains))(*[c.h for c in chains])
     chains[0].L.orc_ns_iterate(arr, len(chains), int(it))
+
+
+def predict_g(bed, mask4, mave, msig, beta):
+    """bayes.cpp:93-122 for one block: bed [M, mbytes] uint8 -> g_k [4*im4]."""
+    bed = np.ascontiguousarray(bed, dtype=np.uint8)
+    M, mbytes = bed.shape
+    mask4 = np.ascontiguousarray(mask4, dtype=np.uint8)
+    g = np.zeros(4 * mbytes, dtype=np.float64)
+    lib().orc_predict_g(_bp(bed), M, mbytes, _bp(mask4), mbytes, _dp(np.ascontiguousarray(mave, dtype=np.float64)),
+                        _dp(np.ascontiguousarray(msig, dtype=np.float64)), _dp(np.ascontiguousarray(beta, dtype=np.float64)), _dp(g))
+    return g
+
+
+def assoc(bed, mask4, y_k):
+    """bayes.cpp:172-196 for one block: xtx, xty per marker (y_k has 4*im4 entries)."""
+    bed = np.ascontiguousarray(bed, dtype=np.uint8)
+    M, mbytes = bed.shape
+    y = np.zeros(4 * mbytes, dtype=np.float64)
+    y[:len(y_k)] = y_k
+    xtx = np.zeros(M, dtype=np.float64)
+    xty = np.zeros(M, dtype=np.float64)
+    lib().orc_assoc(_bp(bed), M, mbytes, _bp(np.ascontiguousarray(mask4, dtype=np.uint8)), mbytes, _dp(y), _dp(xtx), _dp(xty))
+    return xtx, xty
+
+
+def mlma_stats(xtx, xty, sigma):
+    out = [np.zeros(1) for _ in range(4)]
+    lib().orc_mlma_stats(float(xtx), float(xty), float(sigma), *[_dp(o) for o in out])
+    return tuple(float(o[0]) for o in out)
+
+
+def mlma_line(rsid, mglo, rmglo, beta, tdist, se, pval):
+    buf = C.create_string_buffer(256)
+    n = lib().orc_mlma_line(buf, 256, rsid.encode(), int(mglo), int(rmglo), float(beta), float(tdist), float(se), float(pval))
+    return buf.raw[:n]

@@ -1,0 +1,102 @@
+"""Bayes::predict (bayes.cpp:16-284) -- the two device building blocks against the
+oracle's restatement of the reference loops, and bin/gmrm_hip --predict end to end (.bet in,
+fixed-width .mlma out)."""
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import gmrm_amd
+from oracle import orc
+from tests import cases
+from tests.test_gpu_cli import _write_inputs, BIN
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx_with_trait(case, inp, t=0):
+    eps, mask4, nonas = orc.phen_prepare(inp["y"][t], inp["isna"][t])
+    ctx = gmrm_amd.Context(case.N, case.M, T=1)
+    ctx.upload_bed(inp["bed"])
+    ctx.upload_trait(0, eps, mask4, nonas)
+    mave, msig = ctx.compute_markers_statistics(0)
+    return ctx, eps, mask4, nonas, mave, msig
+
+
+@pytest.mark.parametrize("name", ["small", "ragged"])
+def test_predict_g_and_assoc_match_the_reference_loops(gpu, name):
+    case = cases.CASE_BY_NAME[name]
+    inp = cases.make_inputs(case)
+    ctx, eps, mask4, nonas, mave, msig = _ctx_with_trait(case, inp)
+    try:
+        rng = np.random.default_rng(3)
+        beta = rng.normal(0.0, 0.01, size=case.M)
+        beta[rng.random(case.M) < 0.6] = 0.0                      # most posterior means are exactly 0
+        g = ctx.predict_g(0, beta)
+        want = orc.predict_g(inp["bed"], mask4, mave, msig, beta)[:case.N]
+        assert np.array_equal(g, want)                            # same operations in the same (marker) order
+        yk = eps[:case.N] - 0.25 * g
+        xtx, xty = ctx.assoc(0, yk)
+        wxx, wxy = orc.assoc(inp["bed"], mask4, yk)
+        assert np.array_equal(xtx, wxx)                           # integer counts
+        assert np.allclose(xty, wxy, rtol=1e-12, atol=1e-12)      # f64 sums in a different order: 1e-12
+        xtx2, xty2 = ctx.assoc(0, None)                           # default: the residual as uploaded
+        wxx2, wxy2 = orc.assoc(inp["bed"], mask4, eps[:case.N])
+        assert np.array_equal(xtx2, wxx2) and np.allclose(xty2, wxy2, rtol=1e-12, atol=1e-12)
+    finally:
+        ctx.close()
+
+
+def test_cli_predict_writes_the_reference_mlma_records(gpu, tmp_path):
+    assert BIN.exists(), "bin/gmrm_hip not built (python __graft_entry__.py)"
+    case = cases.CASE_BY_NAME["ragged"]
+    inp = cases.make_inputs(case)
+    inp["cva"] = np.array([[float(f"{v:.5f}") for v in row] for row in inp["cva"]])
+    phens = _write_inputs(tmp_path, case, inp)
+    out = tmp_path / "out"
+    common = ["--bed-file", str(tmp_path / "t.bed"), "--dim-file", str(tmp_path / "t.dim"),
+              "--phen-files", ",".join(str(p) for p in phens), "--out-dir", str(out)]
+    r = subprocess.run([str(BIN), *common, "--group-index-file", str(tmp_path / "t.gri"), "--group-mixture-file", str(tmp_path / "t.grm"),
+                        "--seed", str(case.seed), "--iterations", "6", "--output-thin-rate", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # bim files: the current one names every marker; the reference one drops two ids and is rotated
+    ids = [f"rs{1000 + i}" for i in range(case.M)]
+    (tmp_path / "cur.bim").write_text("".join(f"1 {rid} 0 {i + 1} A C\n" for i, rid in enumerate(ids)))
+    ref_ids = ids[5:] + ids[:3] + ["rsX1", "rsX2"]               # ids[3], ids[4] missing; same count as Mtot
+    assert len(ref_ids) == case.M
+    (tmp_path / "ref.bim").write_text("".join(f"1 {rid} 0 {i + 1} A C\n" for i, rid in enumerate(ref_ids)))
+    r = subprocess.run([str(BIN), *common, "--predict", "--bim-file", str(tmp_path / "cur.bim"), "--ref-bim-file", str(tmp_path / "ref.bim")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Number of recorded iterations in .bet file 0: 3" in r.stdout
+    assert f"WARNING: marker id {ids[3]} excluded -- no match" in r.stdout
+    refpos = {rid: i for i, rid in enumerate(ref_ids)}
+    for t in range(inp["y"].shape[0]):
+        eps, mask4, nonas = orc.phen_prepare(inp["y"][t], inp["isna"][t])
+        raw = (out / f"trait{t}.bet").read_bytes()
+        M = struct.unpack("<I", raw[:4])[0]
+        rec = 4 + 8 * M
+        its = [np.frombuffer(raw[4 + k * rec + 4:4 + (k + 1) * rec], dtype="<f8") for k in range(3)]
+        beta_sum = np.zeros(M)
+        for b in its:
+            beta_sum = beta_sum + b
+        beta_sum = beta_sum / 3.0
+        yk = eps[:case.N].copy()                                  # one rank: nothing is left out of y (bayes.cpp:141)
+        sigma = 0.0
+        for v in yk:
+            sigma += v * v
+        sigma /= nonas
+        xtx, xty = orc.assoc(inp["bed"], mask4, yk)
+        lines = (out / f"trait{t}.mlma").read_bytes()
+        kept = [m for m in range(case.M) if ids[m] in refpos]
+        assert len(lines) == 123 * len(kept)
+        for k, m in enumerate(kept):
+            got = lines[123 * k:123 * (k + 1)].decode()
+            f = got.split()
+            assert f[0] == ids[m] and int(f[1]) == m and int(f[2]) == refpos[ids[m]]
+            beta, tdist, se, pval = orc.mlma_stats(xtx[m], xty[m], sigma)
+            assert np.allclose([float(x) for x in f[3:7]], [beta, tdist, se, pval], rtol=0, atol=2e-12)
+            if k < 3:                                             # the record layout itself, byte for byte, from its own numbers
+                assert got.encode() == orc.mlma_line(ids[m], m, refpos[ids[m]], *[float(x) for x in f[3:7]])
