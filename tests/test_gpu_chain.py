@@ -234,3 +234,21 @@ def test_long_chain_stays_bit_exact(gpu):
     print(f"reference-order oracle: components identical for {'all 40' if first is None else first - 1} sweeps")
     if first is None:
         np.testing.assert_allclose(got[0]["betas"][-1], ref[0]["betas"][-1], rtol=1e-6, atol=1e-300)
+
+
+@pytest.mark.parametrize("env", [dict(GMRM_SWEEP_R="2"), dict(GMRM_SWEEP_R="4"),
+                                 dict(GMRM_SPEC_FACTOR16="1"), dict(GMRM_SPEC_FACTOR16="1", GMRM_NB_FACTOR16="64", GMRM_SWEEP_R="2"),
+                                 dict(GMRM_NB_FACTOR16="8")])
+def test_kernel_geometries_and_schedules_give_the_same_chain(gpu, monkeypatch, env):
+    """The results may not depend on how the kernel is laid out or scheduled: bytes per thread
+    R = 1 / 2 / 4 (slice width, ring size, loader mapping, batch cap), speculative next batches
+    forced on (threshold 1/16 batch), larger and smaller batches.  Cases: no missing genotypes
+    (2-value exchange layout, batches up to 120) and 5 % missing (4-value layout)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for case in (cases.Case("geo_fast", 50_000, 900, 1, 4, 1, 0.0, 300, 171014, 3, 20),
+                 cases.Case("geo_general", 20_003, 700, 3, 4, 1, 0.05, 200, 7, 3, 20)):
+        inp = cases.make_inputs(case)
+        got = cases.run_gpu(case, inp)
+        want = cases.run_oracle(case, inp, canon=True)
+        cases.assert_same_history(got, want, exact=True)
