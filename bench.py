@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--markers", type=int, default=0, help="override the total marker count (debug)")
     ap.add_argument("--individuals", type=int, default=0, help="override N (debug)")
+    ap.add_argument("--traits", type=int, default=0, help="override the number of phenotypes (debug)")
     ap.add_argument("--seed", type=int, default=171014)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
@@ -123,6 +124,8 @@ def main():
         Mt = a.markers
     if a.individuals:
         N = a.individuals
+    if a.traits:
+        T = a.traits
     S, M, _ = gmrm_amd.block_of_markers(Mt, world, rank)
 
     t_setup = time.perf_counter()

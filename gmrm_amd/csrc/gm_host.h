@@ -54,7 +54,7 @@ struct gmrm_ctx {
     uint8_t* bed = nullptr;         // Bayes::bed_data, column stride padded to 16 bytes
     int* group = nullptr;           // Bayes::group_index[S .. S+M)
     std::vector<gm::Trait> tr;
-    int num_cu = 0, R = 0, W = 0, Wpad = 0;
+    int num_cu = 0, R = 0, W = 0, Wpad = 0, conc = 1;   // conc: chains that sweep side by side
     bool concurrent = true, have_bed = false, have_groups = false;
     int batch_init = 16, nb_factor16 = 24, spec_factor16 = 64;   // sweep schedule knobs (env GMRM_NB_FACTOR16 / GMRM_SPEC_FACTOR16)
 };
