@@ -82,10 +82,24 @@ def cpu_baseline(ctx, eps, mask4, nonas, cva, seed, target_s):
     ms = int(min(ctx.M, max(probe_ms, target_s / 3.0 / max(per_marker, 1e-9))))
     ms = min(ms, 40_000)
     t_sweep = run(ms, 2)
-    return {"value": ms / t_sweep, "unit": "SNP-updates/s", "cores": threads, "kind": "port",
-            "sample": f"first {ms} markers of the workload x 2 timed sweeps after 1 warm-up, N={N}, "
-                      f"reference-order loops (bayes.cpp:749-766, phenotype.cpp:375-390) with OpenMP, "
-                      f"-Ofast -march=native, OMP_NUM_THREADS={threads}"}
+    out = {"value": ms / t_sweep, "unit": "SNP-updates/s", "cores": threads, "kind": "port",
+           "sample": f"first {ms} markers of the workload x 2 timed sweeps after 1 warm-up, N={N}, "
+                     f"reference-order loops (bayes.cpp:749-766, phenotype.cpp:375-390) with OpenMP, "
+                     f"-Ofast -march=native, OMP_NUM_THREADS={threads}"}
+    # SURVEY 8(d) also asks for the one-thread figure: same loops, OMP_NUM_THREADS = 1, a ~4 s sample
+    try:
+        import ctypes
+        omp = ctypes.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(1)
+        ms1 = max(64, min(ms, int(ms / max(1, threads) / 2)))
+        t1 = run(ms1, 1)
+        omp.omp_set_num_threads(threads)
+        out["value_1_thread"] = ms1 / t1
+        out["sample_1_thread"] = f"first {ms1} markers x 1 timed sweep after 1 warm-up"
+    except Exception as e:                                   # never blocks the headline numbers
+        out["value_1_thread"] = None
+        out["sample_1_thread"] = f"failed: {e!r}"
+    return out
 
 
 def main():
@@ -218,7 +232,10 @@ def main():
                          "kernel_ms_per_launch": kern_ms, "kernel_ms_warmup_launches": warm_ms,
                          "kernel_ms_avg_all_launches": (sum(kern_ms) + sum(warm_ms)) / max(1, len(kern_ms) + len(warm_ms)),
                          "kernel_ms_median": sorted(kern_ms)[len(kern_ms) // 2],
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "measured_stream_read_GBps": (M * ctx.mbytes * T) / t_stats / 1e9 if t_stats > 0 else None,
+                         "measured_stream_note": "gm::k_marker_stats over the same genotype block (one pass, 16-B loads): "
+                                                 "what a pure read stream of this data reaches on this GPU"},
             "sweep": {"updates_per_sweep": upd, "sync_rounds_per_sweep": batches,
                       "update_fraction": [u / float(M) for u in upd]},
             "setup_s": t_setup, "marker_stats_s": t_stats,
