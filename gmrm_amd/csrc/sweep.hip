@@ -648,8 +648,12 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     const int lt = loader ? tid - 64 : 0;
     const int lci = lt % CPP, lpj = lt / CPP;         // chunk of the slice, position within a load instruction
     const size_t cb_true = (size_t)wg * SB + (size_t)lci * 16;
-    const bool lvalid = loader && cb_true < a.stride;
-    const size_t cb = lvalid ? cb_true : 0;           // out-of-range lanes fetch column bytes 0..15 (in bounds, never used)
+    // Out-of-range lanes (last workgroup: its slice sticks out of the column) fetch the same chunk of
+    // the PREVIOUS slice: in bounds, never used (their individuals do not exist), contiguous with the
+    // valid lanes' bytes and in the same page.  The prefetch is TLB-bound (every position is a random
+    // 125 KB column of a 125 GB array): with the surplus lanes on another page of the column the last
+    // workgroup took twice as long to issue its loads and trailed every round by 2 us.
+    const size_t cb = !loader ? 0 : (cb_true < a.stride ? cb_true : (cb_true >= (size_t)SB ? cb_true - SB : cb_true % a.stride));
     auto ring_chunk = [&](int p, int chunk) -> uint4* {   // 16-byte chunk `chunk` of order position p
         return reinterpret_cast<uint4*>(ring + (size_t)((unsigned)p % (unsigned)RPOS) * SB + 16 * (chunk ^ (p & (CPP - 1))));
     };
