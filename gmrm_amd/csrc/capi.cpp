@@ -546,6 +546,7 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
     HIPCHK(hipMemcpy(err, tr.err, sizeof(err), hipMemcpyDeviceToHost));
     if (err[0] == 1) return fail(GMRM_EKERNEL, "sweep kernel: a grid-wide wait timed out (workgroups not co-resident?)");
     if (err[0] == 2) return fail(GMRM_EKERNEL, "sweep kernel: RNG window exhausted inside one batch");
+    if (err[0] == 3) return fail(GMRM_EKERNEL, "sweep kernel: dynamic LDS does not start at offset 0");
     tr.cur ^= 1;
     if (out) {
         long long st[24];

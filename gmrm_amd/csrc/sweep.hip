@@ -523,6 +523,15 @@ __device__ __forceinline__ uint32_t chunk_byte(const uint4& w, int j) {      // 
     const uint32_t ww = j < 4 ? w.x : (j < 8 ? w.y : (j < 12 ? w.z : w.w));
     return (ww >> (8 * (j & 3))) & 0xffu;
 }
+// 4 * (byte k of w) in ONE VALU operation: v_lshlrev_b32 with an SDWA byte select on the shifted operand
+__device__ __forceinline__ uint32_t lut_offset(uint32_t w, int k, uint32_t two) {
+    uint32_t r;
+    if (k == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w));
+    else if (k == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(w));
+    else if (k == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(two), "v"(w));
+    return r;
+}
 // four signed base-256 digits of x (|x| <= 2^30) as the four bytes of the result
 __device__ __forceinline__ uint32_t signed_digits(int x) { return ((uint32_t)x + 0x00808080u) ^ 0x00808080u; }
 // byte p of z0..z3 -> one dword (digit plane p of four individuals)
@@ -570,6 +579,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     unsigned long long* Pg = reinterpret_cast<unsigned long long*>(a.P);
     unsigned long long* Ttg = reinterpret_cast<unsigned long long*>(a.Tt);
 
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) {   // phase A addresses the tables absolutely
+        if (tid == 0) atomicMax(a.err, 3);
+        return;
+    }
     for (int i = tid; i < 624; i += SW_TPB) s_rng0[i] = a.rng_state[i];
     for (int i = tid; i < G * K; i += SW_TPB) s_cass[i] = 0;
     if (tab_in_lds)
@@ -841,39 +854,44 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         const char* prec = planes + ((size_t)sub * nch * 16 + (lane & 15)) * 32;
         int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int bcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        // software pipeline over the thread's 16-byte chunks: the a-values (LUT reads) of chunk c+1, its
-        // plane record and the genotype bytes of chunk c+2 are requested before the 128 dot4 of chunk c
+        // Software pipeline over the thread's 16-byte chunks, two register stages used in turn (no copies).
+        // While the 128 dot4 of one stage run, the other stage is filled one table read per 8 dot4 (the
+        // LGKM counter tracks 15 operations: a burst of 19 reads in front of the dot4 would stall them,
+        // and four wavefronts bursting together would queue on the LDS), its plane record first, the
+        // genotype bytes of the chunk after it half-way through.
         auto chunk_at = [&](int c) { return *reinterpret_cast<const uint4*>(slice + 16 * ((sub * nch + (c < nch ? c : nch - 1)) ^ swz)); };
         auto rec_at = [&](int c, int half) { return *reinterpret_cast<const uint4*>(prec + (size_t)(c < nch ? c : nch - 1) * 512 + 16 * half); };
-        uint4 w1 = chunk_at(0);
-        uint4 pa = rec_at(0, 0), pb = rec_at(0, 1);
-        uint32_t a4[16], b4[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint32_t e = chunk_byte(w1, j);
-            a4[j] = lut_a[e];
-            if (!FAST) b4[j] = lut_b[e];
-        }
-        w1 = chunk_at(1);
-        for (int c = 0; c < nch; c++) {
-            const uint4 pan = rec_at(c + 1, 0), pbn = rec_at(c + 1, 1);
-            uint32_t a4n[16], b4n[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const uint32_t e = chunk_byte(w1, j);
-                a4n[j] = lut_a[e];
-                if (!FAST) b4n[j] = lut_b[e];
+        struct Stage { uint4 pa, pb; uint32_t a4[16], b4[16]; };
+        const uint32_t two = 2u;
+        // absolute LDS addresses (the dynamic LDS block starts at 0, checked at kernel entry): the table
+        // base goes into the instruction's offset field instead of a VALU add per byte
+#define GM_LUT(S, W, J) { const uint32_t off_ = lut_offset((J) < 4 ? W.x : ((J) < 8 ? W.y : ((J) < 12 ? W.z : W.w)), (J) & 3, two);   \
+            S.a4[J] = *(const __attribute__((address_space(3))) uint32_t*)(off_ + (uint32_t)L_LUTA);                                   \
+            if (!FAST) S.b4[J] = *(const __attribute__((address_space(3))) uint32_t*)(off_ + (uint32_t)L_LUTB); }
+#define GM_STEP(CUR, NXT, WN, J) { GM_LUT(NXT, WN, J) GM_DOT8(J, CUR.a4[J], acc, CUR.pa, CUR.pb); if (!FAST) { GM_DOT8(J, CUR.b4[J], bcc, CUR.pa, CUR.pb); } }
+        // dots of stage CUR; fill stage NXT from the bytes WN (chunk CN); fetch the bytes of chunk CN + 1 into WF
+#define GM_RUN(CUR, NXT, WN, CN, WF) {                                                                          \
+            NXT.pa = rec_at(CN, 0); NXT.pb = rec_at(CN, 1);                                                      \
+            asm volatile("s_nop 1" ::: "memory");   /* VALU write -> DPP read of a plane register: 2 wait states */ \
+            GM_STEP(CUR, NXT, WN, 0) GM_STEP(CUR, NXT, WN, 1) GM_STEP(CUR, NXT, WN, 2) GM_STEP(CUR, NXT, WN, 3)      \
+            GM_STEP(CUR, NXT, WN, 4) GM_STEP(CUR, NXT, WN, 5) GM_STEP(CUR, NXT, WN, 6) GM_STEP(CUR, NXT, WN, 7)      \
+            WF = chunk_at((CN) + 1);                                                                             \
+            GM_STEP(CUR, NXT, WN, 8) GM_STEP(CUR, NXT, WN, 9) GM_STEP(CUR, NXT, WN, 10) GM_STEP(CUR, NXT, WN, 11)    \
+            GM_STEP(CUR, NXT, WN, 12) GM_STEP(CUR, NXT, WN, 13) GM_STEP(CUR, NXT, WN, 14) GM_STEP(CUR, NXT, WN, 15) }
+        Stage sa, sb;
+        uint4 wa = chunk_at(0), wb = chunk_at(1);
+        sa.pa = rec_at(0, 0); sa.pb = rec_at(0, 1);
+        GM_LUT(sa, wa, 0) GM_LUT(sa, wa, 1) GM_LUT(sa, wa, 2) GM_LUT(sa, wa, 3) GM_LUT(sa, wa, 4) GM_LUT(sa, wa, 5) GM_LUT(sa, wa, 6) GM_LUT(sa, wa, 7)
+        GM_LUT(sa, wa, 8) GM_LUT(sa, wa, 9) GM_LUT(sa, wa, 10) GM_LUT(sa, wa, 11) GM_LUT(sa, wa, 12) GM_LUT(sa, wa, 13) GM_LUT(sa, wa, 14) GM_LUT(sa, wa, 15)
+        for (int c = 0; c < nch; c += 2) {
+            GM_RUN(sa, sb, wb, c + 1, wa)
+            if (c + 1 < nch) {                        // wave-uniform (nch is 1 or even)
+                GM_RUN(sb, sa, wa, c + 2, wb)
             }
-            w1 = chunk_at(c + 2);
-#define GM_STEP(J) { GM_DOT8(J, a4[J], acc, pa, pb); if (!FAST) { GM_DOT8(J, b4[J], bcc, pa, pb); } }
-            asm volatile("s_nop 1" ::: "memory");   // VALU write -> DPP read of the plane registers (rotation moves): 2 wait states
-            GM_STEP(0) GM_STEP(1) GM_STEP(2) GM_STEP(3) GM_STEP(4) GM_STEP(5) GM_STEP(6) GM_STEP(7)
-            GM_STEP(8) GM_STEP(9) GM_STEP(10) GM_STEP(11) GM_STEP(12) GM_STEP(13) GM_STEP(14) GM_STEP(15)
-#undef GM_STEP
-            pa = pan; pb = pbn;
-#pragma unroll
-            for (int j = 0; j < 16; j++) { a4[j] = a4n[j]; if (!FAST) b4[j] = b4n[j]; }
         }
+#undef GM_RUN
+#undef GM_STEP
+#undef GM_LUT
         if (mk < nb) {                                // digits -> 64-bit sums; sub-slices meet in LDS (integer: exact, any order)
             const long long s1 = (long long)acc[0] + ((long long)acc[1] << 8) + ((long long)acc[2] << 16) + ((long long)acc[3] << 24);
             const long long s2 = (long long)acc[4] + ((long long)acc[5] << 8) + ((long long)acc[6] << 16) + ((long long)acc[7] << 24);
