@@ -257,36 +257,65 @@ __device__ __forceinline__ double decide0(double num, const double* denom_g, con
     return zero_acum ? 0.0 : 1.0 / tmp1;
 }
 // bayes.cpp:450-477: the component search.  Only the lane that stops the walk needs it (a lane
-// whose draw exceeds acum0 ends with a component > 0, i.e. it is the stopping lane).
+// whose draw exceeds acum0 ends with a component > 0, i.e. it is the stopping lane):
+//   for i = 0..K-1: stop at i if prob <= acum or i == K-1; else, unless some |logl[j] - logl[i+1]| > 700
+//   (j > i), acum += 1 / sum_k exp(logl[k] - logl[i+1]).
+// For the stopping lane `s` (wave-uniform) it is computed by the whole wavefront: the (K-1) x K
+// exponentials of the search are independent, so lane i*K + k evaluates term k of step i, lane i sums
+// its row in the reference's order (k = 0..K-1) and forms the increment, and lane s walks the steps.
+// Same operations on the same values as the one-lane version, ~1 exp_ deep instead of K*(K-1).
+__device__ __forceinline__ double readlane64(double x, int l) {   // l wave-uniform: two v_readlane_b32, no LDS crossbar
+    return mk64((unsigned)__builtin_amdgcn_readlane((int)lo32(x), l), (unsigned)__builtin_amdgcn_readlane((int)hi32(x), l));
+}
 template <int K>
-__device__ __forceinline__ void decide_rest(double prob, double acum0, const double (&logl)[K], int& kc, double& acum_v) {
-    double acum = acum0;
-    kc = K - 1;
-    bool done = false;
+__device__ __forceinline__ void decide_rest_wave(int s, double prob, double acum0, const double (&logl)[K], int& kc, double& acum_v) {
+    static_assert(K * (K - 1) <= 64, "one lane per (step, component)");
+    const int lane = threadIdx.x & 63;
+    double ls[K];
 #pragma unroll
-    for (int i = 0; i < K; i++) {
-        if (!done) {
-            if (prob <= acum || i == K - 1) {
-                kc = i;
-                done = true;
-            } else {
-                bool zero_inc = false;
+    for (int k = 0; k < K; k++) ls[k] = readlane64(logl[k], s);      // the stopping lane's log-likelihoods, everywhere
+    const int ti = lane / K, tk = lane % K;                          // this lane's term: step ti, component tk
+    const int ti1 = ti + 1 < K ? ti + 1 : K - 1;
+    double lk = ls[0], lref = ls[0];
 #pragma unroll
-                for (int j = i + 1; j < K; j++)
-                    if (fabs(logl[j] - logl[i + 1 < K ? i + 1 : K - 1]) > 700.0) zero_inc = true;
-                if (!zero_inc) {
-                    double esum = 0.0;
+    for (int j = 1; j < K; j++) { lk = tk == j ? ls[j] : lk; lref = ti1 == j ? ls[j] : lref; }
+    const double d = lk - lref;
+    const double e = (d == 0.0) ? 1.0 : exp_(d);                     // exp_(0) is exactly 1
+    bool zero_inc = false;                                           // of step ti
 #pragma unroll
-                    for (int k = 0; k < K; k++) {
-                        const double d = logl[k] - logl[i + 1 < K ? i + 1 : K - 1];
-                        esum += (d == 0.0) ? 1.0 : exp_(d);
-                    }
-                    acum = acum + 1.0 / esum;
-                }
+    for (int j = 1; j < K; j++)
+        if (j > ti && fabs(ls[j] - lref) > 700.0) zero_inc = true;
+    double incs[K - 1];
+    if constexpr (K == 4) {
+        // a step's four terms sit in one quad: ordered sum ((e0 + e1) + e2) + e3 through DPP quad broadcasts
+        const double esum = ((dpp64<0x00>(e) + dpp64<0x55>(e)) + dpp64<0xAA>(e)) + dpp64<0xFF>(e);
+        const double inc = zero_inc ? 0.0 : 1.0 / esum;              // x + 0.0 == x for the acum values that occur (>= 0)
+#pragma unroll
+        for (int i = 0; i < K - 1; i++) incs[i] = readlane64(inc, i * K);
+    } else {
+        // generic K: lane L < K-1 gathers row L in the reference's order (k = 0..K-1)
+        const int row = lane < K - 1 ? lane : 0;
+        double esum = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; k++) esum += __shfl(e, row * K + k, 64);
+        const bool zi = __shfl((int)zero_inc, row * K, 64) != 0;
+        const double inc = zi ? 0.0 : 1.0 / esum;
+#pragma unroll
+        for (int i = 0; i < K - 1; i++) incs[i] = readlane64(inc, i);
+    }
+    if (lane == s) {
+        double acum = acum0;
+        kc = K - 1;
+        bool done = false;
+#pragma unroll
+        for (int i = 0; i < K; i++) {
+            if (!done) {
+                if (prob <= acum || i == K - 1) { kc = i; done = true; }
+                else acum = acum + incs[i < K - 1 ? i : K - 2];
             }
         }
+        acum_v = acum;
     }
-    acum_v = acum;
 }
 
 // What the sampling wavefront needs about a batch position; lane j holds positions j and j + 64.
@@ -374,11 +403,15 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
         const unsigned long long stop_mask = __ballot(stop);
         const int s = stop_mask ? (__ffsll((long long)stop_mask) - 1) : nbp;
         const int n_done = s < nbp ? s + 1 : nbp;
-        if (s < nbp && lane == s && !(prob <= acum_v)) {                // the component search, one lane
-            decide_rest<K>(prob, acum_v, logl, kc, acum_v);
+        // the component search of the stopping marker (bayes.cpp:450-477), spread over the wavefront
+        const bool need_search = s < nbp && __builtin_amdgcn_readlane((int)!(prob <= acum_v), s < nbp ? s : 0) != 0;   // wave-uniform
+        if (need_search) {
+            decide_rest_wave<K>(s, prob, acum_v, logl, kc, acum_v);
+            if (lane == s) {
 #pragma unroll
-            for (int i = 1; i < K; i++)
-                if (i == kc) { muk_c = muk[i]; denom_c = denom_g[i]; }
+                for (int i = 1; i < K; i++)
+                    if (i == kc) { muk_c = muk[i]; denom_c = denom_g[i]; }
+            }
         }
 
         SSTAMP(2);   // component search
