@@ -101,7 +101,7 @@ template <int R> constexpr int lds_total() {
 }
 static_assert(lds_total<1>() <= 160 * 1024 && lds_total<2>() <= 160 * 1024 && lds_total<4>() <= 160 * 1024, "LDS budget");
 
-enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD };
+enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD, C_TOTF };
 
 size_t sweep_lds_bytes() { return (size_t)lds_total<2>(); }   // the largest of the three carves
 
@@ -637,6 +637,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         ctl[C_CURSOR] = *a.rng_index;
         ctl[C_RNGERR] = 0;
         ctl[C_BAD] = 0;
+        ctl[C_TOTF] = 0;
         ctl[C_EMA] = 16 * a.batch_init / 2;
         ctl[C_NBNEXT] = a.batch_init < 16 ? 16 : (a.batch_init > BMAX ? BMAX : a.batch_init);
     }
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         __syncthreads();
     };
     // request the slices of positions [hi, want) (at most PFN*PPI); they stay in registers until commit
-    auto prefetch_issue = [&](int want) {
+    auto prefetch_issue = [&](int want, unsigned gate_tag) {
         if (want > a.M) want = a.M;
         npf = want - hi;
         if (npf > PFN * PPI) npf = PFN * PPI;
@@ -741,6 +742,16 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                         idx[i] = a.order[p < a.M ? p : a.M - 1];
                     }
                 }
+            }
+            // The column loads miss the TLB (a random 125 KB column of a 125 GB array each) and every memory
+            // instruction of a CU goes through one in-order address pipeline: issued while wavefront 0 polls
+            // for the totals they delay its loads.  So they wait until wavefront 0 has the totals (LDS word);
+            // the marker ids above (L2 hits) are in flight meanwhile.
+            if (gate_tag != 0u) {
+                Spin sp;
+                sp.start();
+                while (*reinterpret_cast<const volatile int*>(&ctl[C_TOTF]) != (int)gate_tag)
+                    if (sp.expired(abort_word)) break;
             }
             // The column loads and their ring writes are inline asm on AGPR operands: the data never
             // passes through compiler-managed registers (which would cost a wait per load), and the
@@ -1037,7 +1048,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // request the slices / sampling inputs the ring can take once the current batch has been
         // walked to its end; wavefronts 1-3 idle through the sampling step below, which hides the
         // marker-id round trip and most of the HBM latency
-        prefetch_issue(pos + cur.nb + RPOS);
+        prefetch_issue(pos + cur.nb + RPOS, cur.gen + 1u);
         meta_issue(pos + cur.nb + META_POS);
         PROF(2);   // prefetch issue
 
@@ -1047,6 +1058,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
             Totals tot0{0.0, 0.0, 0.0, 0.0}, tot1{0.0, 0.0, 0.0, 0.0};
             const bool okw = poll_totals(cur.nb, fast, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word);
+            if (lane == 0) *reinterpret_cast<volatile int*>(&ctl[C_TOTF]) = (int)(cur.gen + 1u);   // the loaders may start
             TRACE(3);
             PROF(4);   // wait for the totals
             bad |= !okw;
