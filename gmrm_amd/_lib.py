@@ -61,6 +61,11 @@ SIGNATURES = {
     "gmrm_upload_bed": (C.c_int, [VP, c_u8_p, C.c_size_t, C.c_size_t]),
     "gmrm_load_bed_file": (C.c_int, [VP, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(IngestStatsC)]),
     "gmrm_download_bed": (C.c_int, [VP, c_u8_p, C.c_size_t, C.c_size_t]),
+    "gmrm_group_create": (C.c_int, [C.POINTER(VP), C.c_int, C.POINTER(VP), C.POINTER(VP), C.c_int, C.c_int, C.c_int]),
+    "gmrm_group_uses_rccl": (C.c_int, [VP]),
+    "gmrm_group_iterate": (C.c_int, [VP, C.c_int]),
+    "gmrm_group_destroy": (C.c_int, [VP]),
+    "gmrm_rccl_selftest": (C.c_int, [C.c_int]),
     "gmrm_predict_g": (C.c_int, [VP, C.c_int, c_double_p, c_double_p]),
     "gmrm_assoc": (C.c_int, [VP, C.c_int, c_double_p, c_double_p, c_double_p]),
     "gmrm_synth_bed": (C.c_int, [VP, C.c_uint64, C.c_double, C.c_double]),

@@ -12,7 +12,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libgmrm_hip.so"
-SOURCES = ["ops.hip", "sweep.hip", "capi.cpp", "sampler.cpp", "ingest.cpp"]
+SOURCES = ["ops.hip", "sweep.hip", "capi.cpp", "sampler.cpp", "ingest.cpp", "shard_group.cpp"]
 HEADERS = ["gm_common.h", "gm_rng.h", "gm_internal.h", "gm_host.h", "zig_tables.h", "../../include/gmrm_hip.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",
          "-Wno-unused-function"]

@@ -1,0 +1,218 @@
+// shard_group.cpp -- several marker shards (one context + sampler per GPU) driven by ONE host
+// process: the sweep-synchronous schedule of DESIGN.md "Multi-GPU" behind a C ABI, for hosts that
+// are not Python (bin/gmrm_hip --devices 0,1,...).  gmrm_amd/dist.py is the same schedule with one
+// process per GPU under torch.distributed.
+//
+// Reference: the MPI calls inside Bayes::process (src/bayes.cpp:495-553 per marker step,
+// :575-588 per sweep).  Here, per iteration:
+//   1. every shard draws mu on its own stream; shard 0's draw is used            (bayes.cpp:348-351)
+//   2. every shard launches its marker loop (persistent kernel, asynchronous)
+//   3. per phenotype the pre-rounded residual changes of all shards are summed:
+//      ONE all-reduce of 2 x 4 ceil(N/4) doubles (RCCL ncclAllReduce over xGMI; exact sums, so the
+//      result does not depend on RCCL's reduction order)
+//   4. cass summed, beta_sqn summed in shard order                                (bayes.cpp:575-588)
+//   5. every shard runs the hyper-parameter draws, then adopts shard 0's          (bayes.cpp:626,638,649)
+// RCCL is opened with dlopen (librccl.so) only when asked for: nothing else in the library needs
+// it, and a Python host already carries its own copy.  Without it (or when two shards share a
+// device, as in the one-GPU tests) the exchange is staged through host memory.
+#include "../../include/gmrm_hip.h"
+#include "gm_host.h"
+
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+using gm::fail;
+
+namespace {
+// the few RCCL entry points used, by their public C signatures (rccl.h)
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;                 // ncclSuccess == 0
+constexpr int kNcclFloat64 = 8;           // ncclDataType_t: ncclDouble / ncclFloat64
+constexpr int kNcclSum = 0;               // ncclRedOp_t: ncclSum
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool open() {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h) return false;
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(h, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(h, "ncclAllReduce"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllReduce;
+    }
+};
+}  // namespace
+
+struct gmrm_group {
+    int n = 0, T = 0, G = 0, K = 0;
+    size_t nq = 0;                            // doubles per exchange buffer: 2 * 4 * ceil(N/4)
+    std::vector<gmrm_ctx*> ctx;
+    std::vector<gmrm_sampler*> smp;
+    std::vector<double*> q;                   // per shard, on its device
+    std::vector<hipStream_t> st;
+    std::vector<ncclComm_t> comm;
+    Rccl rccl;
+    bool use_rccl = false;
+    std::vector<double> hq, hsum;             // host staging
+    double exchange_ms = 0.0;
+};
+
+#define HIPG(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(GMRM_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" int gmrm_group_create(gmrm_group** out, int n, gmrm_ctx** ctxs, gmrm_sampler** smps, int G, int K, int want_rccl) {
+    if (!out || !ctxs || !smps || n < 1) return fail(GMRM_EINVAL, "bad argument");
+    gmrm_group* g = new gmrm_group();
+    g->n = n; g->G = G; g->K = K;
+    g->ctx.assign(ctxs, ctxs + n);
+    g->smp.assign(smps, smps + n);
+    g->T = ctxs[0]->T;
+    g->nq = 2 * 4 * ctxs[0]->mbytes;
+    bool distinct = true;
+    for (int r = 0; r < n; r++) {
+        if (ctxs[r]->N != ctxs[0]->N || ctxs[r]->T != g->T) { delete g; return fail(GMRM_EINVAL, "shards disagree on N or T"); }
+        for (int s = 0; s < r; s++) if (ctxs[s]->device == ctxs[r]->device) distinct = false;
+    }
+    g->q.assign(n, nullptr);
+    g->st.assign(n, nullptr);
+    for (int r = 0; r < n; r++) {
+        HIPG(hipSetDevice(ctxs[r]->device));
+        HIPG(hipMalloc(reinterpret_cast<void**>(&g->q[r]), g->nq * sizeof(double)));
+        HIPG(hipStreamCreateWithFlags(&g->st[r], hipStreamNonBlocking));
+    }
+    if (n > 1 && want_rccl && distinct && g->rccl.open()) {
+        std::vector<int> devs(n);
+        for (int r = 0; r < n; r++) devs[r] = ctxs[r]->device;
+        g->comm.assign(n, nullptr);
+        if (g->rccl.CommInitAll(g->comm.data(), n, devs.data()) == 0) g->use_rccl = true;
+        else g->comm.clear();
+    }
+    if (!g->use_rccl) { g->hq.resize(g->nq); g->hsum.resize(g->nq); }
+    *out = g;
+    return GMRM_OK;
+}
+
+extern "C" int gmrm_group_uses_rccl(const gmrm_group* g) { return g && g->use_rccl ? 1 : 0; }
+
+extern "C" int gmrm_group_destroy(gmrm_group* g) {
+    if (!g) return GMRM_OK;
+    for (int r = 0; r < g->n; r++) {
+        (void)hipSetDevice(g->ctx[r]->device);
+        if (g->use_rccl && g->comm[r]) g->rccl.CommDestroy(g->comm[r]);
+        if (g->q[r]) (void)hipFree(g->q[r]);
+        if (g->st[r]) (void)hipStreamDestroy(g->st[r]);
+    }
+    if (g->rccl.h) dlclose(g->rccl.h);
+    delete g;
+    return GMRM_OK;
+}
+
+// sum the n exchange buffers (same length, one per shard) and leave the total in each
+static int allreduce_q(gmrm_group* g) {
+    const int n = g->n;
+    if (g->use_rccl) {
+        if (g->rccl.GroupStart() != 0) return fail(GMRM_EHIP, "ncclGroupStart failed");
+        for (int r = 0; r < n; r++) {
+            HIPG(hipSetDevice(g->ctx[r]->device));
+            const ncclResult_t rc = g->rccl.AllReduce(g->q[r], g->q[r], g->nq, kNcclFloat64, kNcclSum, g->comm[r], g->st[r]);
+            if (rc != 0) return fail(GMRM_EHIP, std::string("ncclAllReduce: ") + (g->rccl.GetErrorString ? g->rccl.GetErrorString(rc) : "error"));
+        }
+        if (g->rccl.GroupEnd() != 0) return fail(GMRM_EHIP, "ncclGroupEnd failed");
+        for (int r = 0; r < n; r++) {
+            HIPG(hipSetDevice(g->ctx[r]->device));
+            HIPG(hipStreamSynchronize(g->st[r]));
+        }
+        return GMRM_OK;
+    }
+    std::fill(g->hsum.begin(), g->hsum.end(), 0.0);
+    for (int r = 0; r < n; r++) {                               // exact bins: any order gives the same bits
+        HIPG(hipSetDevice(g->ctx[r]->device));
+        HIPG(hipMemcpy(g->hq.data(), g->q[r], g->nq * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < g->nq; i++) g->hsum[i] += g->hq[i];
+    }
+    for (int r = 0; r < n; r++) {
+        HIPG(hipSetDevice(g->ctx[r]->device));
+        HIPG(hipMemcpy(g->q[r], g->hsum.data(), g->nq * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return GMRM_OK;
+}
+
+extern "C" int gmrm_group_iterate(gmrm_group* g, int it) {
+    if (!g) return fail(GMRM_EINVAL, "null group");
+    const int n = g->n, T = g->T, G = g->G, K = g->K;
+    std::vector<double> mu0(T), mu(T);
+    for (int r = 0; r < n; r++)
+        if (int rc = gmrm_sampler_draw_mu(g->smp[r], it, r == 0 ? mu0.data() : mu.data())) return rc;
+    for (int r = 0; r < n; r++)
+        if (int rc = gmrm_sampler_begin_sweep(g->smp[r], mu0.data())) return rc;      // launches; returns at once
+    std::vector<int> cass((size_t)T * G * K, 0), c1((size_t)T * G * K);
+    std::vector<double> bsq((size_t)T * G, 0.0), b1((size_t)T * G);
+    for (int r = 0; r < n; r++) {
+        if (int rc = gmrm_sampler_end_sweep(g->smp[r], c1.data(), b1.data())) return rc;
+        for (size_t i = 0; i < cass.size(); i++) cass[i] += c1[i];
+        for (size_t i = 0; i < bsq.size(); i++) bsq[i] += b1[i];                        // shard order, as a sequential MPI_SUM would
+    }
+    if (n > 1) {
+        for (int t = 0; t < T; t++) {
+            for (int r = 0; r < n; r++)
+                if (int rc = gmrm_eps_delta_export(g->ctx[r], t, g->q[r])) return rc;
+            if (int rc = allreduce_q(g)) return rc;
+            for (int r = 0; r < n; r++)
+                if (int rc = gmrm_eps_delta_import(g->ctx[r], t, g->q[r])) return rc;
+        }
+    }
+    for (int r = 0; r < n; r++)
+        if (int rc = gmrm_sampler_epilogue(g->smp[r], cass.data(), bsq.data())) return rc;
+    for (int t = 0; t < T; t++) {
+        gmrm_hyper h;
+        if (int rc = gmrm_sampler_get(g->smp[0], t, &h)) return rc;
+        for (int r = 1; r < n; r++)
+            if (int rc = gmrm_sampler_adopt(g->smp[r], t, h.sigmag, h.pi_est, h.sigmae)) return rc;
+    }
+    return GMRM_OK;
+}
+
+// One-rank exercise of the dlopen'ed RCCL entry points (signatures, enum values, stream use) on
+// `device`: all-reduce of a small f64 buffer in place.  The multi-GPU exchange itself needs several
+// devices; this is what a one-GPU box can check of it.
+extern "C" int gmrm_rccl_selftest(int device) {
+    Rccl r;
+    if (!r.open()) return fail(GMRM_ENODEV, "librccl.so could not be opened");
+    int rc = GMRM_OK;
+    ncclComm_t comm = nullptr;
+    double* d = nullptr;
+    hipStream_t st = nullptr;
+    const int n = 1000;
+    std::vector<double> h(n), back(n);
+    for (int i = 0; i < n; i++) h[i] = 0.5 * i - 3.0;
+    do {
+        if (hipSetDevice(device) != hipSuccess) { rc = fail(GMRM_EHIP, "hipSetDevice"); break; }
+        if (r.CommInitAll(&comm, 1, &device) != 0) { rc = fail(GMRM_EHIP, "ncclCommInitAll failed"); break; }
+        if (hipMalloc(reinterpret_cast<void**>(&d), n * sizeof(double)) != hipSuccess) { rc = fail(GMRM_EHIP, "hipMalloc"); break; }
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rc = fail(GMRM_EHIP, "hipStreamCreate"); break; }
+        if (hipMemcpy(d, h.data(), n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(GMRM_EHIP, "hipMemcpy"); break; }
+        if (r.GroupStart() != 0 || r.AllReduce(d, d, n, kNcclFloat64, kNcclSum, comm, st) != 0 || r.GroupEnd() != 0) { rc = fail(GMRM_EHIP, "ncclAllReduce failed"); break; }
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = fail(GMRM_EHIP, "hipStreamSynchronize"); break; }
+        if (hipMemcpy(back.data(), d, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(GMRM_EHIP, "hipMemcpy"); break; }
+        if (std::memcmp(h.data(), back.data(), n * sizeof(double)) != 0) rc = fail(GMRM_EKERNEL, "one-rank ncclAllReduce changed the data");
+    } while (0);
+    if (st) (void)hipStreamDestroy(st);
+    if (d) (void)hipFree(d);
+    if (comm) r.CommDestroy(comm);
+    dlclose(r.h);
+    return rc;
+}

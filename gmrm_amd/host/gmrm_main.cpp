@@ -39,6 +39,8 @@ struct Opts {
     bool shuffle = true, mimic_hydra = false, predict = false;
     unsigned seed = 0, iterations = 1, truncm = 0, thin = 1;
     int device = 0;
+    std::vector<int> devices;     // --devices a,b,...: one marker shard per entry (this build only)
+    bool no_rccl = false;
 };
 
 [[noreturn]] void fatal(const std::string& m) {
@@ -117,6 +119,20 @@ Opts parse(int argc, char** argv) {
         else if (a == "--bim-file") { last(i); o.bim_file = argv[++i]; ss << "--bim-file " << o.bim_file << "\n"; }
         else if (a == "--ref-bim-file") { last(i); o.ref_bim_file = argv[++i]; ss << "--ref-bim-file " << o.ref_bim_file << "\n"; }
         else if (a == "--device") { last(i); o.device = atoi(argv[++i]); ss << "--device " << o.device << "\n"; }   // this build only
+        else if (a == "--devices") {                                       // this build only: marker shards, one per listed GPU
+            last(i);
+            std::stringstream sl(argv[++i]);
+            std::string d;
+            while (getline(sl, d, ',')) o.devices.push_back(atoi(d.c_str()));
+            ss << "--devices " << argv[i] << "\n";
+        }
+        else if (a == "--gpus") {                                          // this build only: --devices 0,1,...,n-1
+            last(i);
+            const int n = atoi(argv[++i]);
+            for (int d = 0; d < n; d++) o.devices.push_back(d);
+            ss << "--gpus " << n << "\n";
+        }
+        else if (a == "--no-rccl") { o.no_rccl = true; ss << "--no-rccl 1\n"; }   // this build only: stage the exchange through the host
         else fatal("FATAL: option \"" + a + "\" unknown");
     }
     std::cout << ss.str() << std::endl;
@@ -307,19 +323,37 @@ int main(int argc, char** argv) {
 
     if (gmrm_device_count() < 1) fatal("FATAL  : no HIP device visible; this build has no CPU path.");
     const int T = (int)opt.phen_files.size();
-    printf("INFO   : rank %4d has %d markers over tot Mt = %d, max Mm = %d, starting at S = %d\n", 0, Mt, Mt, Mt, 0);
-    gmrm_ctx* ctx = nullptr;
-    need(gmrm_ctx_create(&ctx, opt.device, N, Mt, Mt, 0, T), "gmrm_ctx_create");
+    // Marker shards, one per GPU, by the reference's block rule (Bayes::set_block_of_markers,
+    // bayes.cpp:903-925): what MPI ranks are upstream.  `ctx` / `smp` below are shard 0.
+    std::vector<int> devs = opt.devices.empty() ? std::vector<int>{opt.device} : opt.devices;
+    const int nsh = (int)devs.size();
+    if (opt.predict && nsh > 1) fatal("FATAL  : --predict runs on one GPU in this build.");
+    std::vector<int> S_(nsh), M_(nsh);
+    {
+        const int modu = Mt % nsh, size = Mt / nsh, Mm = modu != 0 ? size + 1 : size;
+        int at = 0;
+        for (int r = 0; r < nsh; r++) {
+            M_[r] = r < modu ? size + 1 : size; S_[r] = at; at += M_[r];
+            printf("INFO   : rank %4d has %d markers over tot Mt = %d, max Mm = %d, starting at S = %d\n", r, M_[r], Mt, Mm, S_[r]);
+        }
+    }
+    std::vector<gmrm_ctx*> ctxs(nsh, nullptr);
+    for (int r = 0; r < nsh; r++) need(gmrm_ctx_create(&ctxs[r], devs[r], N, M_[r], Mt, S_[r], T), "gmrm_ctx_create");
+    gmrm_ctx* ctx = ctxs[0];
 
     // bayes.cpp:867-900: marker-major block after 3 magic bytes (validated by the library; upstream skips
     // them unchecked).  Parallel chunked pread -> pinned ring -> copy engine, gmrm_amd/csrc/ingest.cpp.
     const size_t mbytes = ((size_t)N + 3) / 4;
     {
         printf("INFO   : rank %4d has allocated %zu bytes (%.3f GB) for raw data.\n", 0, (size_t)Mt * mbytes, double((size_t)Mt * mbytes) / 1.0E9);
-        gmrm_ingest_stats st;
+        gmrm_ingest_stats st, tot{};
         const unsigned hw = std::thread::hardware_concurrency();
-        if (gmrm_load_bed_file(ctx, opt.bed_file.c_str(), 0, (int)std::min(16u, std::max(1u, hw)), &st) != GMRM_OK)
-            fatal(std::string("FATAL  : ") + gmrm_last_error());
+        for (int r = 0; r < nsh; r++) {
+            if (gmrm_load_bed_file(ctxs[r], opt.bed_file.c_str(), (size_t)S_[r], (int)std::min(16u, std::max(1u, hw)), &st) != GMRM_OK)
+                fatal(std::string("FATAL  : ") + gmrm_last_error());
+            tot.bytes += st.bytes; tot.seconds += st.seconds; tot.read_seconds += st.read_seconds; tot.threads = st.threads;
+        }
+        st = tot;
         printf("INFO   : time to load genotype data = %.2f seconds.\n", st.seconds);
         printf("INFO   : genotype ingest %.3f GB at %.2f GB/s (%d reader threads, %.2f s inside pread).\n",
                double(st.bytes) / 1.0E9, st.seconds > 0 ? double(st.bytes) / st.seconds / 1.0E9 : 0.0, st.threads, st.read_seconds);
@@ -350,7 +384,7 @@ int main(int argc, char** argv) {
         int nonas = 0;
         need(gmrm_phen_prepare(y.data(), isna.data(), N, eps.data(), mask4.data(), &nonas), "gmrm_phen_prepare");
         if (N % 4 != 0) std::cout << "Setting last " << 4 - N % 4 << " bits to NAs" << std::endl;
-        need(gmrm_upload_trait(ctx, t, eps.data(), mask4.data(), nonas), "gmrm_upload_trait");
+        for (int r = 0; r < nsh; r++) need(gmrm_upload_trait(ctxs[r], t, eps.data(), mask4.data(), nonas), "gmrm_upload_trait");
         printf("INFO   : %s has %d NAs and %d non-NAs.\n", opt.phen_files[t].c_str(), N - nonas, nonas);
         stems.push_back(stem_of(opt.phen_files[t]));
         if (opt.predict) { eps0.push_back(eps); nonas_t.push_back(nonas); }
@@ -384,16 +418,25 @@ int main(int argc, char** argv) {
         group_index.resize(Mt);
     }
 
-    gmrm_sampler_opts so{};
-    so.seed = opt.seed; so.rank = 0; so.nranks = 1; so.shuffle = opt.shuffle; so.mimic_hydra = opt.mimic_hydra;
-    so.G = G; so.K = K; so.cva = cva.data(); so.group_index = group_index.data();
-    gmrm_sampler* smp = nullptr;
+    std::vector<gmrm_sampler*> smps(nsh, nullptr);
     {
         const double ts = now();
-        need(gmrm_sampler_create(&smp, ctx, &so), "gmrm_sampler_create");   // computes the markers' statistics
+        for (int r = 0; r < nsh; r++) {
+            gmrm_sampler_opts so{};
+            so.seed = opt.seed; so.rank = r; so.nranks = nsh; so.shuffle = opt.shuffle; so.mimic_hydra = opt.mimic_hydra;
+            so.G = G; so.K = K; so.cva = cva.data(); so.group_index = group_index.data();
+            need(gmrm_sampler_create(&smps[r], ctxs[r], &so), "gmrm_sampler_create");   // computes the markers' statistics
+        }
         printf("INFO   : Time to compute the markers' statistics: %.2f seconds.\n", now() - ts);
     }
-    need(gmrm_sampler_init(smp), "gmrm_sampler_init");
+    for (int r = 0; r < nsh; r++) need(gmrm_sampler_init(smps[r]), "gmrm_sampler_init");
+    gmrm_sampler* smp = smps[0];
+    gmrm_group* grp = nullptr;
+    if (nsh > 1) {                                                           // replaces the MPI calls of Bayes::process
+        need(gmrm_group_create(&grp, nsh, ctxs.data(), smps.data(), G, K, opt.no_rccl ? 0 : 1), "gmrm_group_create");
+        printf("INFO   : %d marker shards, residual exchange once per sweep through %s.\n", nsh,
+               gmrm_group_uses_rccl(grp) ? "RCCL (ncclAllReduce)" : "host memory");
+    }
 
     // phenotype.cpp:129-143: <out_dir>/<phen stem>.{bet,cpn,csv}
     std::vector<HistFile> fbet(T), fcpn(T), fcsv(T);
@@ -410,7 +453,8 @@ int main(int argc, char** argv) {
     for (unsigned it = 1; it <= opt.iterations; it++) {
         const double ts = now();
         printf("\n\n@@@ ITERATION %5d\n", it);
-        need(gmrm_sampler_iterate(smp, (int)it), "gmrm_sampler_iterate");
+        if (grp) need(gmrm_group_iterate(grp, (int)it), "gmrm_group_iterate");
+        else need(gmrm_sampler_iterate(smp, (int)it), "gmrm_sampler_iterate");
         for (int t = 0; t < T; t++) {
             gmrm_hyper h;
             need(gmrm_sampler_get(smp, t, &h), "gmrm_sampler_get");
@@ -425,8 +469,10 @@ int main(int argc, char** argv) {
                 const int n = gmrm_sampler_csv_line(smp, t, (int)it, line.data(), line.size());
                 need(n, "gmrm_sampler_csv_line");
                 fcsv[t].put(line.data(), (size_t)n, (off_t)nth * n);        // xfiles.cpp:45
-                need(gmrm_get_betas(ctx, t, betas.data()), "gmrm_get_betas");
-                need(gmrm_get_comp(ctx, t, comp.data()), "gmrm_get_comp");
+                for (int r = 0; r < nsh; r++) {                             // each shard's block at its global offset S
+                    need(gmrm_get_betas(ctxs[r], t, betas.data() + S_[r]), "gmrm_get_betas");
+                    need(gmrm_get_comp(ctxs[r], t, comp.data() + S_[r]), "gmrm_get_comp");
+                }
                 if (nth == 0) { fbet[t].put(&Mtot, 4, 0); fcpn[t].put(&Mtot, 4, 0); }
                 const off_t ob = 4 + (off_t)nth * (4 + (off_t)Mtot * 8), oc = 4 + (off_t)nth * (4 + (off_t)Mtot * 4);
                 fbet[t].put(&it, 4, ob); fbet[t].put(betas.data(), (size_t)Mtot * 8, ob + 4);
@@ -436,7 +482,7 @@ int main(int argc, char** argv) {
         fflush(stdout);
     }
     for (int t = 0; t < T; t++) { close(fbet[t].fd); close(fcpn[t].fd); close(fcsv[t].fd); }
-    gmrm_sampler_destroy(smp);
-    gmrm_ctx_destroy(ctx);
+    if (grp) gmrm_group_destroy(grp);
+    for (int r = 0; r < nsh; r++) { gmrm_sampler_destroy(smps[r]); gmrm_ctx_destroy(ctxs[r]); }
     return 0;
 }

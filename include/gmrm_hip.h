@@ -216,6 +216,22 @@ int gmrm_sampler_get(gmrm_sampler* s, int t, gmrm_hyper* out);
 /* one .csv record of phenotype t as write_ofile_csv formats it (src/xfiles.cpp:17-42) */
 int gmrm_sampler_csv_line(gmrm_sampler* s, int t, int it, char* buf, size_t len);
 
+/* ------------------------------------------------------------------------------------
+ * Several marker shards in ONE host process (one context + sampler per GPU): the per-sweep
+ * exchange that replaces the MPI calls of Bayes::process (src/bayes.cpp:495-553,575-588) -- one
+ * all-reduce of the residual per phenotype and sweep (RCCL ncclAllReduce over xGMI when
+ * `want_rccl` and every shard has its own device; staged through host memory otherwise).
+ * ctxs[r] / smps[r]: shard r, created with opts.rank = r, opts.nranks = n.  The group borrows them.
+ * gmrm_group_iterate = one iteration of every phenotype on every shard.
+ * ---------------------------------------------------------------------------------- */
+typedef struct gmrm_group gmrm_group;
+int gmrm_group_create(gmrm_group** out, int n, gmrm_ctx** ctxs, gmrm_sampler** smps, int G, int K, int want_rccl);
+int gmrm_group_uses_rccl(const gmrm_group* g);
+int gmrm_group_iterate(gmrm_group* g, int it);
+int gmrm_group_destroy(gmrm_group* g);
+/* one-rank exercise of the RCCL entry points the group uses (what a one-GPU box can check) */
+int gmrm_rccl_selftest(int device);
+
 #ifdef __cplusplus
 }
 #endif
