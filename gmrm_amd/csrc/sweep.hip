@@ -697,8 +697,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     const size_t cb_true = (size_t)wg * SB + (size_t)lci * 16;
     // Out-of-range lanes (last workgroup: its slice sticks out of the column) fetch the same chunk of
     // the PREVIOUS slice: in bounds, never used (their individuals do not exist), contiguous with the
-    // valid lanes' bytes and in the same page.  The prefetch is TLB-bound (every position is a random
-    // 125 KB column of a 125 GB array): with the surplus lanes on another page of the column the last
+    // valid lanes' bytes.  The prefetch issue is latency-bound per column (every position is a random
+    // 125 KB column of a 125 GB array): with the surplus lanes at the other end of the column the last
     // workgroup took twice as long to issue its loads and trailed every round by 2 us.
     const size_t cb = !loader ? 0 : (cb_true < a.stride ? cb_true : (cb_true >= (size_t)SB ? cb_true - SB : cb_true % a.stride));
     auto ring_chunk = [&](int p, int chunk) -> uint4* {   // 16-byte chunk `chunk` of order position p
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     }
                 }
             }
-            // The column loads miss the TLB (a random 125 KB column of a 125 GB array each) and every memory
+            // The column loads are slow to issue (a random 125 KB column of a 125 GB array each) and every memory
             // instruction of a CU goes through one in-order address pipeline: issued while wavefront 0 polls
             // for the totals they delay its loads.  So they wait until wavefront 0 has the totals (LDS word);
             // the marker ids above (L2 hits) are in flight meanwhile.
