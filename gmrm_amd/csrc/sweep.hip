@@ -31,27 +31,29 @@
 //
 // Pipelining.  While the totals of batch g are in flight, every wavefront already computes and
 // publishes the dots of batch g+1, assuming g ends without a residual update; g+1 is then
-// promoted, otherwise discarded and a fresh batch starts after the stopping marker.  Speculation
-// is switched on only when the recent run length makes P(no update) >~ 1/2.
+// promoted, otherwise discarded and a fresh batch starts after the stopping marker.  A miss costs a
+// whole batch of dots, so this is switched on only when the recent run length is several batches
+// (spec_factor16; at the measured update rates it rarely is).
 //
 // Genotype stream.  The visit order is known for the whole sweep, so each workgroup keeps a ring
 // of RPOS column slices in LDS (16-byte chunks XOR-swizzled by position so that 64 lanes reading
-// 64 different slices hit different banks).  Wavefronts 1-2 fetch the slices of upcoming positions
-// as coalesced 16-byte loads one round ahead, hold them in registers while the round runs and park
-// them in the ring once the sampled batch has released its slots.  (Individuals without a phenotype
+// 64 different slices hit different banks).  Wavefronts 1-3 fetch the slices of upcoming positions
+// as coalesced 16-byte loads during the sampling step (in which they are otherwise idle), hold them
+// in AGPRs and park them in the ring once the sampled batch has released its slots.  (Individuals without a phenotype
 // have residual 0, hence all-zero digit planes: phase A needs no mask; the update applies it.)
 // Wavefront 3 does the same for the per-marker inputs of the sampling step (marker id, group,
 // previous effect, mave, msig).
 //
 // Exchange per batch (placement-independent, gfx950: private L2 per XCD).  "The data is the
-// flag": every exchanged double travels as two 8-byte granules {tag = generation + 1,
-// 32 data bits}, each written by ONE sc1 (write-through) store and read by sc1 loads until
-// the tag matches -- no counters, no fences.  Generation g uses buffer g & 1.
+// flag": every exchanged double travels as two 8-byte granules {32 data bits, tag = generation + 1}
+// side by side, written by ONE 16-byte sc1 (write-through) store and read by 16-byte sc1 loads
+// until both tags match -- no counters, no fences.  Generation g uses buffer g & 1.
 //   1. every workgroup stores its partial sums (4 per marker, or 2 per marker + 2 per batch in
 //      the no-missing-genotype layout) to P[g&1][v][wg];
 //   2. workgroup v polls row v, reduces it (exact sums: any order), stores the total Tt[g&1][v];
-//   3. wavefront 0 of EVERY workgroup polls the totals and runs the SAME sampling step on the
-//      SAME RNG stream (kept in LDS) -- redundant, hence no broadcast hop.
+//   3. wavefront 0 of EVERY workgroup fetches the whole row of totals (one round trip per look) and
+//      runs the SAME sampling step on the SAME RNG stream (kept in LDS) -- redundant, hence no
+//      broadcast hop.
 // Every spin is bounded (wall-clock timeout -> error word -> all workgroups leave).
 #include "gm_common.h"
 #include "gm_rng.h"
