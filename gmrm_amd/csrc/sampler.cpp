@@ -26,6 +26,7 @@ struct Chain {                       // class Phenotype, the host-resident part
     double sigmae = 0.0, mu = 0.0, epssum = 0.0;
     long long n_updates = 0, n_batches = 0;
     double sweep_ms = 0.0;
+    bool preshuffled = false;        // midx already holds the NEXT iteration's order (shuffled while the GPU swept)
 };
 
 }  // namespace
@@ -99,6 +100,7 @@ int gmrm_sampler_init(gmrm_sampler* s) {
     if (!s) return fail(GMRM_EINVAL, "null sampler");
     for (auto& c : s->ch) {
         for (int i = 0; i < s->ctx->M; i++) c.midx[i] = i;                         // phenotype.cpp:308-312
+        c.preshuffled = false;
         for (int g = 0; g < s->G; g++) {
             c.sigmag[g] = gm::rbeta(c.dist_d, 1.0, 1.0);
             if (s->mtotgrp[g] == 0) c.sigmag[g] = 0.0;
@@ -131,7 +133,8 @@ int gmrm_sampler_begin_sweep(gmrm_sampler* s, const double* mu_use) {
         Chain& c = s->ch[t];
         c.mu = mu_use[t];
         if (int r = gmrm_offset_eps(ctx, t, -c.mu)) return r;
-        if (s->shuffle) gm::shuffle(s->mimic_hydra ? c.dist_d : c.dist_m, c.midx.data(), ctx->M);   // phenotype.cpp:314-323
+        if (s->shuffle && !c.preshuffled) gm::shuffle(s->mimic_hydra ? c.dist_d : c.dist_m, c.midx.data(), ctx->M);   // phenotype.cpp:314-323
+        c.preshuffled = false;
         std::fill(c.m0.begin(), c.m0.end(), 0);
         std::fill(c.cass.begin(), c.cass.end(), 0);
         if (s->nranks > 1)
@@ -150,6 +153,16 @@ int gmrm_sampler_begin_sweep(gmrm_sampler* s, const double* mu_use) {
         in.rng_index = c.dist_d.idx;
         if (int r = gmrm_sweep_launch(ctx, t, &in)) return r;
     }
+    // The marker loops are running on the GPU (the order was copied at launch).  The next iteration's
+    // shuffle draws from dist_m only, a stream nothing else reads (phenotype.cpp:314-323): do it now, on
+    // the idle host, instead of in front of the next launch (~5 ms per million markers).  Not with
+    // --mimic-hydra, where the shuffle shares dist_d with the hyper-parameter draws of this iteration.
+    if (s->shuffle && !s->mimic_hydra)
+        for (int t = 0; t < ctx->T; t++) {
+            Chain& c = s->ch[t];
+            gm::shuffle(c.dist_m, c.midx.data(), ctx->M);
+            c.preshuffled = true;
+        }
     return GMRM_OK;
 }
 
