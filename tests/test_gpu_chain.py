@@ -252,3 +252,16 @@ def test_kernel_geometries_and_schedules_give_the_same_chain(gpu, monkeypatch, e
         got = cases.run_gpu(case, inp)
         want = cases.run_oracle(case, inp, canon=True)
         cases.assert_same_history(got, want, exact=True)
+
+
+@pytest.mark.parametrize("K", [2, 5, 8])
+def test_mixture_counts_other_than_the_examples(gpu, K):
+    """K = 2 .. 8 mixture components per group (options.cpp:222-286 puts no bound on it; this build
+    supports up to 8): the out-of-line sampling step and the wavefront-wide component search
+    (one lane per (step, component): K (K-1) <= 56 lanes) against the oracle, bit for bit."""
+    case = cases.Case(f"k{K}", 6_001, 500, 2, K, 1, 0.02, 40, 11 + K, 4, 40)
+    inp = cases.make_inputs(case)
+    got = cases.run_gpu(case, inp)
+    want = cases.run_oracle(case, inp, canon=True)
+    cases.assert_same_history(got, want, exact=True)
+    assert max(int(np.max(c)) for c in got[0]["comp"]) >= 1          # some marker left component 0
