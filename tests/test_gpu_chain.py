@@ -265,3 +265,15 @@ def test_mixture_counts_other_than_the_examples(gpu, K):
     want = cases.run_oracle(case, inp, canon=True)
     cases.assert_same_history(got, want, exact=True)
     assert max(int(np.max(c)) for c in got[0]["comp"]) >= 1          # some marker left component 0
+
+
+@pytest.mark.parametrize("G,K", [(40, 4), (64, 8)])
+def test_many_groups_tables_beyond_the_lds_budget(gpu, G, K):
+    """G (1 + 3K) > 320 doubles: the per-group tables (sigmag, denominators, log pi, -log/2 terms) no
+    longer fit their LDS slot and the sampling step reads them from HBM/L2; G = 64, K = 8 are the
+    largest supported.  Several groups stay empty or tiny (bayes.cpp:329-330,594-595)."""
+    case = cases.Case(f"g{G}", 5_003, 700, G, K, 1, 0.03, 25, 5 + G, 3, 30)
+    inp = cases.make_inputs(case)
+    got = cases.run_gpu(case, inp)
+    want = cases.run_oracle(case, inp, canon=True)
+    cases.assert_same_history(got, want, exact=True)
