@@ -207,3 +207,41 @@ def test_sharded_schedule_single_rank_is_plain_iterate():
     assert not np.array_equal(a[0]["betas"][-1], b[0]["betas"][-1])
     assert 0.1 < b[0]["sigmae"][-1] < 2.0
     assert np.all(np.isfinite(b[0]["eps"]))
+
+
+def test_predict_restatement_against_numpy():
+    """Bayes::predict's loops (bayes.cpp:93-122, 172-205, 233-234) as restated in the oracle, checked
+    against a direct numpy evaluation of the same formulas on decoded genotypes (no GPU)."""
+    import math
+    from tests import cases
+    case = cases.Case("pred", 203, 37, 1, 4, 1, 0.06, 9, 3, 1, 5)
+    inp = cases.make_inputs(case)
+    eps, mask4, nonas = orc.phen_prepare(inp["y"][0], inp["isna"][0])
+    N, M = case.N, case.M
+    n4 = inp["bed"].shape[1]
+    code = np.stack([(inp["bed"] >> (2 * k)) & 3 for k in range(4)], axis=2).reshape(M, 4 * n4)
+    a = np.select([code == 0, code == 2], [2.0, 1.0], 0.0)
+    b = (code != 1).astype(np.float64)
+    na = np.zeros(4 * n4)
+    na[:N] = 1.0 - inp["isna"][0]
+    mave = (a * na).sum(1) / (b * na).sum(1)
+    msig = 1.0 / np.sqrt((((a - mave[:, None]) * b * na) ** 2).sum(1) / (nonas - 1))
+    rng = np.random.default_rng(4)
+    beta = rng.normal(0, 0.02, size=M)
+    beta[::3] = 0.0
+    g = orc.predict_g(inp["bed"], mask4, mave, msig, beta)
+    want_g = (((a - mave[:, None]) * b * na * msig[:, None]) * beta[:, None]).sum(0)
+    assert np.allclose(g, want_g, rtol=1e-12, atol=1e-14)
+    yk = eps - 0.5 * g
+    xtx, xty = orc.assoc(inp["bed"], mask4, yk)
+    assert np.array_equal(xtx, ((a * b * na) ** 2).sum(1))
+    assert np.allclose(xty, (a * b * na * yk).sum(1), rtol=1e-12, atol=1e-13)
+    sigma = float((yk[:N] ** 2).sum() / nonas)
+    bt, td, se, pv = orc.mlma_stats(xtx[5], xty[5], sigma)
+    assert bt == xty[5] / xtx[5] and td == xty[5] / math.sqrt(sigma * xtx[5]) and se == bt / td
+    assert abs(pv - math.erfc(abs(td) / math.sqrt(2.0))) < 1e-15      # 1 - gamma_p(1/2, t^2/2) = erfc(|t|/sqrt 2)
+    line = orc.mlma_line("rs12562034", 7, 11, bt, td, se, pv)
+    assert len(line) == 123 and line.endswith(b"\n")
+    f = line.split()
+    assert f[0] == b"rs12562034" and int(f[1]) == 7 and int(f[2]) == 11
+    assert [float(x) for x in f[3:]] == pytest.approx([bt, td, se, pv], abs=5e-16)
