@@ -364,7 +364,7 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
 #endif
     int cursor = rs.cursor;                      // wave-uniform: RNG words consumed so far
     int run = 2 * nb;                            // markers walked, for the batch-size estimate
-    bool stopped = false;
+    bool stopped = false, planned = false;
 #pragma unroll 1
     for (int part = 0; part < 2; part++) {                           // one copy of the code (instruction cache)
         const int base = 64 * part;
@@ -450,7 +450,13 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
             ctl[C_NDONE] = base + n_done;
         }
         SSTAMP(3);   // commit + stop lane
-        if (s < nbp) { stopped = true; run = base + s + 1; }
+        if (s < nbp) {
+            stopped = true;
+            run = base + s + 1;
+            // a stop at a marker with a non-zero effect was planned (the batch ends there by construction,
+            // see compute_publish): it says nothing about how long a batch may usefully be
+            planned = __builtin_amdgcn_readlane((int)(beta_old != 0.0), s) != 0;
+        }
         else cursor = cursor0 + __popcll(use_mask);
     }
     if (!stopped && lane == 0) {
@@ -458,7 +464,7 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
         ctl[C_CURSOR] = cursor;
         ctl[C_NDONE] = nb;
     }
-    if (lane == 0) {                                                 // next batch size from the recent run length
+    if (lane == 0 && !planned) {                                     // next batch size from the recent run length
         const int ema = (3 * ctl[C_EMA] + 16 * run) / 4;            // fixed point, 1/16 marker
         ctl[C_EMA] = ema;
         const int want = nbf16 * ema / 256;
@@ -876,7 +882,18 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // phase A for positions [b.p0, b.p0 + b.nb) (slices already in the ring) + publish
     auto compute_publish = [&](Batch& b, LaneIn& li0, LaneIn& li1) {
         lds_barrier();                                // ring / plane / meta writes are visible (no vmcnt drain)
-        const int nb = b.nb, p0 = b.p0;
+        const int p0 = b.p0;
+        // A marker whose effect is non-zero always changes it (bayes.cpp:479-483: the new draw differs), so
+        // the walk is known to stop there: end the batch at the first such marker instead of computing dots
+        // behind it that are certain to go stale.  (Every wavefront scans the same LDS words: uniform.)
+        {
+            const bool nz0 = lane < b.nb && mr_beta[(p0 + lane) & (META_POS - 1)] != 0.0;
+            const bool nz1 = lane + 64 < b.nb && mr_beta[(p0 + lane + 64) & (META_POS - 1)] != 0.0;
+            const unsigned long long m0 = __ballot(nz0), m1 = __ballot(nz1);
+            const int first = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : b.nb);
+            if (first + 1 < b.nb) b.nb = first + 1;
+        }
+        const int nb = b.nb;
         li0 = LaneIn{0, 0, 0.0, 0.0, 1.0};
         li1 = LaneIn{0, 0, 0.0, 0.0, 1.0};
         if (wave == 0 && lane < nb) {
