@@ -869,7 +869,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // the reducers); otherwise it is discarded and a fresh batch starts after the stopping
     // marker.  Generation g uses tag g+1 and buffer g&1; a buffer is rewritten only after every
     // workgroup has sampled the generation that used it.
-    struct Batch { int p0, nb, nv; unsigned gen; };
+    struct Batch { int p0, nb, nv; unsigned gen; bool planned; };   // planned: ends at a marker known to stop the walk
     unsigned gen_next = 0;
     long long n_upd = 0, n_batch = 0, n_disc = 0;
     int max_nb = 0;
@@ -892,6 +892,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const unsigned long long m0 = __ballot(nz0), m1 = __ballot(nz1);
             const int first = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : b.nb);
             if (first + 1 < b.nb) b.nb = first + 1;
+            b.planned = first < b.nb;                 // the last marker of the batch has a non-zero effect
         }
         const int nb = b.nb;
         li0 = LaneIn{0, 0, 0.0, 0.0, 1.0};
@@ -1014,7 +1015,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         return bad;
     };
 
-    Batch cur{0, 0, 0, 0u}, nxt{0, 0, 0, 0u}, tb{0, 0, 0, 0u};
+    Batch cur{0, 0, 0, 0u, false}, nxt{0, 0, 0, 0u, false}, tb{0, 0, 0, 0u, false};
     LaneIn li_cur0{0, 0, 0.0, 0.0, 1.0}, li_cur1{0, 0, 0.0, 0.0, 1.0}, li_nxt0{0, 0, 0.0, 0.0, 1.0}, li_nxt1{0, 0, 0.0, 0.0, 1.0};
     bool bad = false;
     {
@@ -1037,7 +1038,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             if (nb0 > a.M - pos) nb0 = a.M - pos;
             tb.p0 = pos; tb.nb = nb0; tb.gen = gen_next++;
             do_compute = true;
-        } else if (ctl[C_EMA] >= a.spec_factor16 * cur.nb) {   // speculate only when the recent run length (1/16 units)
+        } else if (!cur.planned && ctl[C_EMA] >= a.spec_factor16 * cur.nb) {   // never behind a certain stop; else only when the recent run length (1/16 units)
             const int p1 = pos + cur.nb;              // is long enough: P(no residual update) >~ 1/2
             if (p1 < a.M) {
                 int nb1 = ctl[C_NBNEXT];
