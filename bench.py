@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=171014)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
+    ap.add_argument("--no-signal", action="store_true", help="skip the signal-bearing extra block")
+    ap.add_argument("--signal-sweeps", type=int, default=8, help="sweeps of the signal-bearing chain (first 2 reported apart)")
     return ap.parse_args()
 
 
@@ -102,6 +104,62 @@ def cpu_baseline(ctx, eps, mask4, nonas, cva, seed, target_s):
     return out
 
 
+def signal_block(ctx, gmrm_amd, np, N, Mt, cva, group_index, seed, sweeps):
+    """The same genotypes with a phenotype that carries signal (example/data_sim.R:18-41): 0.5 % of the
+    markers causal, effects ~ N(0, h2 / n_causal) on standardised genotypes, h2 = 0.5, y = g + e.  The
+    genetic values g come from the device (gmrm_predict_g, the product's own kernel).  Reported beside
+    the headline (null) workload: with signal more visits change an effect, and every change costs one
+    exchange round, so throughput moves with the update rate."""
+    rng = np.random.default_rng(seed + 1)
+    n_causal = max(1, Mt // 200)
+    beta = np.zeros(ctx.M)
+    idx = rng.choice(ctx.M, size=min(n_causal, ctx.M), replace=False)
+    beta[idx] = rng.normal(0.0, np.sqrt(0.5 / n_causal), size=len(idx))
+    g = ctx.predict_g(0, beta)
+    vg = float(np.var(g))
+    y = g + rng.normal(0.0, np.sqrt(max(1e-6, 1.0 - vg)), size=N)
+    eps, mask4, nonas = gmrm_amd.prepare_phenotype(y, np.zeros(N, dtype=np.uint8))
+    ctx.upload_trait(0, eps, mask4, nonas)
+    ctx.compute_markers_statistics(0)
+    smp = gmrm_amd.Sampler(ctx, seed, cva, group_index)
+    ms, upd, rounds = [], [], []
+    t0 = time.perf_counter()
+    for it in range(1, sweeps + 1):
+        smp.iterate(it)
+        hy = smp.hyper(0)
+        ms.append(hy.sweep_device_ms); upd.append(hy.n_updates); rounds.append(hy.n_batches)
+    wall = time.perf_counter() - t0
+    hy = smp.hyper(0)
+    smp.close()
+    tail = ms[2:] if len(ms) > 2 else ms
+    return {"workload": f"same genotypes, y = X beta + e: {len(idx)} causal markers (0.5 %), h2 = 0.5 (var(g) = {vg:.3f}), "
+                        f"{sweeps} sweeps from an all-zero start",
+            "value_after_2_sweeps": ctx.M / (sum(tail) / len(tail) / 1e3), "unit": "SNP-updates/s (kernel time)",
+            "kernel_ms_per_sweep": ms, "updates_per_sweep": upd, "sync_rounds_per_sweep": rounds,
+            "update_fraction": [u / float(ctx.M) for u in upd], "first_two_sweeps_ms": ms[:2], "wall_s": wall,
+            "sigmaG_final": float(np.sum(hy.sigmag)), "sigmaE_final": float(hy.sigmae)}
+
+
+def launcher_command(ngpus, argv, port):
+    """The command `python bench.py --gpus N ...` re-launches itself with (one rank per GPU, RCCL)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+
+
+def self_launch(ngpus):
+    import socket
+    import subprocess
+    with socket.socket() as sk:                      # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = launcher_command(ngpus, sys.argv[1:], port)
+    print("[bench] launching:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,8 +167,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    if a.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver calls it: start one rank per GPU under
+        # torch.distributed.run as a CHILD process and relay its output and exit code.  Nothing in
+        # this process has imported torch or touched the GPU yet (never exec from a process that has).
+        raise SystemExit(self_launch(a.gpus))
     # CPU-baseline threads: the GPU box's CPU share for one GPU is 16 hardware threads; fixed
     # here, before any OpenMP runtime starts (no OMP_PROC_BIND: it would pin this thread too).
     global CPU_THREADS
@@ -194,10 +255,15 @@ def main():
         batches.append(hy.n_batches)
     fence()
     dt = time.perf_counter() - t0
+    per_gpu_kernel_ms = [sum(kern_ms) / max(1, len(kern_ms))]
     if use_pg:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        km = torch.tensor(per_gpu_kernel_ms, dtype=torch.float64, device=dev)
+        allk = [torch.zeros_like(km) for _ in range(world)]
+        dist.all_gather(allk, km)
+        per_gpu_kernel_ms = [float(x.item()) for x in allk]
 
     if rank == 0:
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (it cannot
@@ -238,6 +304,13 @@ def main():
                                                  "what a pure read stream of this data reaches on this GPU"},
             "sweep": {"updates_per_sweep": upd, "sync_rounds_per_sweep": batches,
                       "update_fraction": [u / float(M) for u in upd]},
+            "rccl_ranks": world if use_pg else 0,
+            "per_gpu": {"kernel_ms_avg": per_gpu_kernel_ms,
+                        "roofline_frac": [(float(gmrm_amd.block_of_markers(Mt, world, r)[1]) * mbytes / (k / 1e3) / 1e9 / HBM_PEAK_GBS) if k > 0 else 0.0
+                                          for r, k in enumerate(per_gpu_kernel_ms)],
+                        "note": "every shard sweeps its block against its own residual replica; one exact residual "
+                                "all-reduce per sweep (RCCL) -- a sweep-synchronous approximation of the sequential scan, "
+                                "not the reference's per-step exchange (DESIGN.md section 6)" if world > 1 else None},
             "setup_s": t_setup, "marker_stats_s": t_stats,
             "marker_stats_GBps": (M * ctx.mbytes * T) / t_stats / 1e9 if t_stats > 0 else None,
         }
@@ -249,6 +322,12 @@ def main():
             except Exception as e:                               # the baseline never blocks the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "SNP-updates/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e!r}"}
+        if world == 1 and T == 1 and not a.no_signal and a.signal_sweeps > 0:
+            try:
+                smp.close()
+                out["extra"] = {"signal_bearing": signal_block(ctx, gmrm_amd, np, N, Mt, cva, group_index, a.seed, a.signal_sweeps)}
+            except Exception as e:                               # never blocks the headline numbers
+                out["extra"] = {"signal_bearing": {"failed": repr(e)}}
         print(json.dumps(out), flush=True)
     smp.close()
     ctx.close()

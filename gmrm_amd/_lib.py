@@ -44,6 +44,10 @@ class HyperC(C.Structure):
                 ("n_updates", C.c_longlong), ("n_batches", C.c_longlong), ("sweep_device_ms", C.c_double)]
 
 
+class GeometryC(C.Structure):
+    _fields_ = [("R", C.c_int), ("W", C.c_int), ("conc", C.c_int), ("num_cu", C.c_int), ("max_resident_wg", C.c_int)]
+
+
 class IngestStatsC(C.Structure):
     _fields_ = [("bytes", C.c_size_t), ("seconds", C.c_double), ("read_seconds", C.c_double),
                 ("threads", C.c_int), ("chunk_bytes", C.c_size_t)]
@@ -58,6 +62,7 @@ SIGNATURES = {
     "gmrm_ctx_create": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gmrm_ctx_destroy": (C.c_int, [VP]),
     "gmrm_ctx_sync": (C.c_int, [VP]),
+    "gmrm_ctx_geometry": (C.c_int, [VP, C.POINTER(GeometryC)]),
     "gmrm_upload_bed": (C.c_int, [VP, c_u8_p, C.c_size_t, C.c_size_t]),
     "gmrm_load_bed_file": (C.c_int, [VP, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(IngestStatsC)]),
     "gmrm_download_bed": (C.c_int, [VP, c_u8_p, C.c_size_t, C.c_size_t]),

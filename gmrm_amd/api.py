@@ -90,6 +90,12 @@ class Context:
             pass
 
     # ---- genotypes: Bayes::load_genotype (src/bayes.cpp:867-900) ----
+    def geometry(self):
+        """Launch geometry of the persistent sweep kernel (R bytes per thread, W workgroups, conc chains side by side)."""
+        g = _lib.GeometryC()
+        check(self.lib.gmrm_ctx_geometry(self.h, C.byref(g)))
+        return dict(R=g.R, W=g.W, conc=g.conc, num_cu=g.num_cu, max_resident_wg=g.max_resident_wg)
+
     def upload_bed(self, cols, first=0):
         cols = np.ascontiguousarray(cols, dtype=np.uint8)
         if cols.ndim != 2 or cols.shape[1] != self.mbytes:

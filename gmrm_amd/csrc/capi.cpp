@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,6 +30,25 @@ template <class T> static hipError_t dalloc(T** p, size_t n) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
     if (e != hipSuccess) return e;
     return hipMemset(*p, 0, n * sizeof(T));
+}
+
+// ---- co-residency bookkeeping ---------------------------------------------------------------
+// The sweep kernel's workgroups wait for each other inside the launch, so every workgroup of every
+// sweep that is running on a device must be resident at the same time.  Launches are counted per
+// DEVICE (two contexts may share one, e.g. `--devices 0,0`): a launch that would not fit beside the
+// sweeps already in flight there first waits for them (they then simply run one after another).
+struct InFlight { const gmrm_ctx* ctx; int t; hipStream_t stream; int wgs; };
+static std::mutex g_dev_mu;
+static std::map<int, std::vector<InFlight>> g_dev_inflight;
+
+static int device_inflight_wgs(int device, const gmrm_ctx* c) {
+    // a context runs at most `conc` of its own launches at once (the others queue behind them on the
+    // same streams); other contexts' launches are counted in full
+    int own = 0, others = 0;
+    for (const InFlight& f : g_dev_inflight[device]) {
+        if (f.ctx == c) own++; else others += f.wgs;
+    }
+    return others + std::min(own, c->conc) * c->W;
 }
 
 int ctx_check_t(const gmrm_ctx* c, int t) {
@@ -50,22 +71,10 @@ int gmrm_device_count(void) {
     return n;
 }
 
-int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int T) {
-    if (!out) return fail(GMRM_EINVAL, "out is null");
-    *out = nullptr;
-    if (N < 2 || M < 0 || Mt < M || S < 0 || S + M > Mt || T < 1 || T > 64)
-        return fail(GMRM_EINVAL, "bad dimensions");
-    if (((long long)N + 3) / 4 > (1ll << gm::MAX_LOG2_N) / 4)
-        return fail(GMRM_EINVAL, "N exceeds 2^22 individuals (limit of the exact-summation bins)");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(GMRM_ENODEV, "no HIP device visible: libgmrm_hip has no CPU path");
-    if (device < 0 || device >= ndev) return fail(GMRM_EINVAL, "device index out of range");
+static int ctx_create_body(gmrm_ctx* c, int device, int N, int M, int Mt, int S, int T) {
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
-
-    gmrm_ctx* c = new gmrm_ctx();
     c->device = device; c->N = N; c->M = M; c->Mt = Mt; c->S = S; c->T = T;
     c->mbytes = ((size_t)N + 3) / 4;                          // bayes.cpp:776
     c->stride = (c->mbytes + 15) / 16 * 16;
@@ -84,7 +93,11 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
         if (r > 0) { c->R = r; c->W = w; c->conc = cc; break; }
     }
     c->concurrent = c->conc == T;
-    if (c->R < 0) { delete c; return fail(GMRM_EINVAL, "N too large for the resident-residual sweep kernel"); }
+    if (c->R < 0) {
+        const long long lim = (long long)std::min(c->num_cu, SW_TPB) * SW_TPB * 4 * 4;
+        return fail(GMRM_EINVAL, "N too large for the resident-residual sweep kernel on this device: the limit is "
+                                 + std::to_string(lim) + " individuals (compute units x 256 threads x 4 bytes x 4 individuals per byte)");
+    }
     if (const char* e = std::getenv("GMRM_SWEEP_R")) {        // diagnostic override of the bytes-per-thread choice
         const int r = std::atoi(e);
         if ((r == 1 || r == 2 || r == 4) && (size_t)r * SW_TPB * 256 >= c->stride && r >= c->R) {
@@ -92,13 +105,25 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
         }
     }
     c->Wpad = (c->W + 15) / 16 * 16;
+    // Co-residency: every workgroup of the `conc` launches must be resident at once (they wait for
+    // each other).  Ask the runtime how many the device holds instead of assuming one per CU.
+    {
+        int per_cu = 0;
+        HIPCHK(sweep_occupancy(c->R, &per_cu));
+        c->max_resident_wg = per_cu * c->num_cu;
+        if (c->W * c->conc > c->max_resident_wg)
+            return fail(GMRM_EINVAL, "sweep geometry cannot be co-resident: " + std::to_string(c->W) + " workgroups x " +
+                                     std::to_string(c->conc) + " chains > " + std::to_string(c->max_resident_wg) +
+                                     " resident workgroups (occupancy query x compute units)");
+    }
     if (const char* e = std::getenv("GMRM_NB_FACTOR16")) { int v = std::atoi(e); if (v >= 8 && v <= 256) c->nb_factor16 = v; }
     if (const char* e = std::getenv("GMRM_SPEC_FACTOR16")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) c->spec_factor16 = v; }
+    if (const char* e = std::getenv("GMRM_SPIN_TIMEOUT_MS")) { int v = std::atoi(e); if (v >= 1 && v <= 60000) c->spin_timeout_ms = v; }
 
     hipError_t e = hipSuccess;
     const size_t bedbytes = (size_t)(M > 0 ? M : 1) * c->stride;
     e = hipMalloc(reinterpret_cast<void**>(&c->bed), bedbytes);
-    if (e != hipSuccess) { delete c; return fail(GMRM_ENOMEM, std::string("hipMalloc(bed): ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) return fail(GMRM_ENOMEM, std::string("hipMalloc(bed): ") + hipGetErrorString(e));
     HIPCHK(hipMemset(c->bed, 0, bedbytes));
     HIPCHK(dalloc(&c->group, (size_t)(M > 0 ? M : 1)));
     c->tr.resize(T);
@@ -133,13 +158,47 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
     // The zero-fills above run on the null stream and may still be in flight; every later
     // operation runs on non-blocking streams, which do not wait for the null stream.
     HIPCHK(hipDeviceSynchronize());
+    return GMRM_OK;
+}
+
+int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int T) {
+    if (!out) return fail(GMRM_EINVAL, "out is null");
+    *out = nullptr;
+    if (N < 2 || M < 0 || Mt < M || S < 0 || S + M > Mt || T < 1 || T > 64)
+        return fail(GMRM_EINVAL, "bad dimensions");
+    if (((long long)N + 3) / 4 > (1ll << gm::MAX_LOG2_N) / 4)
+        return fail(GMRM_EINVAL, "N exceeds 2^22 individuals (limit of the exact-summation bins)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(GMRM_ENODEV, "no HIP device visible: libgmrm_hip has no CPU path");
+    if (device < 0 || device >= ndev) return fail(GMRM_EINVAL, "device index out of range");
+    gmrm_ctx* c = new gmrm_ctx();
+    c->device = device;
+    const int rc = ctx_create_body(c, device, N, M, Mt, S, T);
+    if (rc != GMRM_OK) {                                      // release whatever was allocated before the failure
+        const std::string keep = g_err;
+        gmrm_ctx_destroy(c);
+        g_err = keep;
+        return rc;
+    }
     *out = c;
+    return GMRM_OK;
+}
+
+int gmrm_ctx_geometry(const gmrm_ctx* c, gmrm_geometry* out) {
+    if (!c || !out) return fail(GMRM_EINVAL, "null argument");
+    out->R = c->R; out->W = c->W; out->conc = c->conc; out->num_cu = c->num_cu; out->max_resident_wg = c->max_resident_wg;
     return GMRM_OK;
 }
 
 int gmrm_ctx_destroy(gmrm_ctx* c) {
     if (!c) return GMRM_OK;
     hipSetDevice(c->device);
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        auto& v = g_dev_inflight[c->device];
+        v.erase(std::remove_if(v.begin(), v.end(), [&](const InFlight& f) { return f.ctx == c; }), v.end());
+    }
     for (auto& tr : c->tr) {
         if (tr.stream) hipStreamSynchronize(tr.stream);
         hipFree(tr.eps); hipFree(tr.eps_start); hipFree(tr.namask2); hipFree(tr.mave); hipFree(tr.msig); hipFree(tr.nomiss);
@@ -240,6 +299,7 @@ int gmrm_upload_trait(gmrm_ctx* c, int t, const double* eps, const uint8_t* mask
     tr.nonas = nonas;
     tr.have_trait = true;
     tr.have_stats = false;
+    tr.poisoned = false;
     return GMRM_OK;
 }
 
@@ -452,6 +512,9 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     if (!tr.have_stats) return fail(GMRM_ESTATE, "marker statistics not computed (gmrm_marker_stats)");
     if (!c->have_groups) return fail(GMRM_ESTATE, "marker groups not set (gmrm_set_groups)");
     if (tr.in_flight) return fail(GMRM_ESTATE, "a sweep of this phenotype is already in flight");
+    if (tr.poisoned)
+        return fail(GMRM_ESTATE, "an earlier sweep of this phenotype failed inside the kernel: its per-marker outputs are "
+                                 "partly written; upload the phenotype again (gmrm_upload_trait) before sweeping");
     const int G = in->G, K = in->K;
     if (G < 1 || G > GMAX || K < 2 || K > KMAX) return fail(GMRM_EINVAL, "G or K outside the supported range (G<=64, 2<=K<=8)");
     if (in->rng_index < 0 || in->rng_index > 624) return fail(GMRM_EINVAL, "rng_index out of range");
@@ -519,11 +582,31 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.nb_factor16 = c->nb_factor16;
     a.spec_factor16 = c->spec_factor16;
     a.all_nomiss = tr.all_nomiss;
+    a.spin_ticks = (unsigned long long)c->spin_timeout_ms * 100000ull;      // s_memrealtime ticks (100 MHz)
     // Phenotypes that do not fit side by side share stream 0 and run one after another.
     hipStream_t st = c->tr[t % c->conc].stream;       // conc chains side by side, the others queue behind them
     if (t % c->conc != t) HIPCHK(hipStreamSynchronize(tr.stream));           // uploads above done
+    // Co-residency across contexts that share this device: wait for sweeps that would not fit beside this one.
+    {
+        std::unique_lock<std::mutex> lk(g_dev_mu);
+        auto& v = g_dev_inflight[c->device];
+        v.push_back(InFlight{c, t, st, c->W});
+        while (device_inflight_wgs(c->device, c) > c->max_resident_wg) {
+            auto it = std::find_if(v.begin(), v.end(), [&](const InFlight& f) { return f.ctx != c; });
+            if (it == v.end()) break;                   // only this context's own launches: they queue on its streams
+            const hipStream_t other = it->stream;
+            v.erase(it);                                // its owner's gmrm_sweep_finish still synchronises the stream
+            lk.unlock();
+            HIPCHK(hipStreamSynchronize(other));
+            lk.lock();
+        }
+    }
+    int grid = c->W;
+    if (const char* e = std::getenv("GMRM_FAULT_DROP_WG")) {                 // test hook: launch one workgroup short, so the
+        if (std::atoi(e) > 0 && grid > 1) grid -= 1;                         // grid-wide wait can never complete (timeout path)
+    }
     HIPCHK(hipEventRecord(tr.ev0, st));
-    HIPCHK(launch_sweep(a, c->R, st));
+    HIPCHK(launch_sweep(a, c->R, st, grid));
     HIPCHK(hipEventRecord(tr.ev1, st));
     tr.launch_stream = st;
     tr.in_flight = true;
@@ -542,11 +625,24 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
     }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(tr.launch_stream));
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        auto& v = g_dev_inflight[c->device];
+        auto it = std::find_if(v.begin(), v.end(), [&](const InFlight& f) { return f.ctx == c && f.t == t; });
+        if (it != v.end()) v.erase(it);
+    }
     int err[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(err, tr.err, sizeof(err), hipMemcpyDeviceToHost));
-    if (err[0] == 1) return fail(GMRM_EKERNEL, "sweep kernel: a grid-wide wait timed out (workgroups not co-resident?)");
-    if (err[0] == 2) return fail(GMRM_EKERNEL, "sweep kernel: RNG window exhausted inside one batch");
-    if (err[0] == 3) return fail(GMRM_EKERNEL, "sweep kernel: dynamic LDS does not start at offset 0");
+    if (err[0] != 0) {
+        // the kernel left before storing the residual, the RNG state and the new effects' buffer was not
+        // adopted (tr.cur unchanged) -- but comp / acum are partly overwritten: the chain state is unusable
+        tr.poisoned = true;
+        if (err[0] == 1) return fail(GMRM_EKERNEL, "sweep kernel: a grid-wide wait timed out (workgroups not co-resident?)");
+        if (err[0] == 2) return fail(GMRM_EKERNEL, "sweep kernel: RNG window exhausted inside one batch");
+        if (err[0] == 3) return fail(GMRM_EKERNEL, "sweep kernel: dynamic LDS does not start at offset 0");
+        if (err[0] == 4) return fail(GMRM_EKERNEL, "sweep kernel: |residual| reached 2^8 inside the sweep: outside the range of the exact-summation bins");
+        return fail(GMRM_EKERNEL, "sweep kernel: unknown error code " + std::to_string(err[0]));
+    }
     tr.cur ^= 1;
     if (out) {
         long long st[24];

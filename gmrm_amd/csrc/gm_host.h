@@ -23,6 +23,7 @@ struct Trait {
     double* acum = nullptr;         // Phenotype::acum [M]
     int nonas = 0;
     bool have_trait = false, have_stats = false, in_flight = false, empty = false;
+    bool poisoned = false;          // a sweep failed inside the kernel: comp / acum partly written, sweeps refused until re-upload
     int all_nomiss = 0;             // every marker of the block: nomiss == 1
     int G = 0, K = 0;
     // sweep workspace
@@ -55,6 +56,8 @@ struct gmrm_ctx {
     int* group = nullptr;           // Bayes::group_index[S .. S+M)
     std::vector<gm::Trait> tr;
     int num_cu = 0, R = 0, W = 0, Wpad = 0, conc = 1;   // conc: chains that sweep side by side
+    int max_resident_wg = 0;        // occupancy query x num_cu for the sweep kernel at this R
+    int spin_timeout_ms = 4000;     // bound of every grid-wide wait inside the kernel (env GMRM_SPIN_TIMEOUT_MS)
     bool concurrent = true, have_bed = false, have_groups = false;
     int batch_init = 16, nb_factor16 = 24, spec_factor16 = 64;   // sweep schedule knobs (env GMRM_NB_FACTOR16 / GMRM_SPEC_FACTOR16)
 };

@@ -47,10 +47,12 @@ struct SweepArgs {
     int nb_factor16;               // next batch >= nb_factor16/16 x the run-length EMA, as a power of two (default 24 = 1.5x)
     int spec_factor16;             // speculate when EMA >= spec_factor16/16 batches (default 64 = 4x: rarely pays)
     int all_nomiss;                // 1: no marker of this block has a missing genotype among the phenotyped individuals
+    unsigned long long spin_ticks; // every grid-wide wait gives up after this many s_memrealtime ticks (100 MHz)
 };
 
 // sweep.hip
-hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st);
+hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid);   // grid == a.W (tests may launch one short)
+hipError_t sweep_occupancy(int R, int* blocks_per_cu);                          // resident workgroups per CU (runtime query)
 int  sweep_pick_R(size_t stride, int max_wg, int* W_out);   // bytes per thread, or -1
 size_t sweep_lds_bytes();
 

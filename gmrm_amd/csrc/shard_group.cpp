@@ -74,9 +74,24 @@ struct gmrm_group {
 
 #define HIPG(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(GMRM_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
+static int group_create_body(gmrm_group* g, int n, gmrm_ctx** ctxs, gmrm_sampler** smps, int G, int K, int want_rccl);
+
 extern "C" int gmrm_group_create(gmrm_group** out, int n, gmrm_ctx** ctxs, gmrm_sampler** smps, int G, int K, int want_rccl) {
     if (!out || !ctxs || !smps || n < 1) return fail(GMRM_EINVAL, "bad argument");
+    *out = nullptr;
     gmrm_group* g = new gmrm_group();
+    const int rc = group_create_body(g, n, ctxs, smps, G, K, want_rccl);
+    if (rc != GMRM_OK) {                                      // release the buffers / streams made before the failure
+        const std::string keep = gmrm_last_error();
+        gmrm_group_destroy(g);
+        fail(rc, keep);
+        return rc;
+    }
+    *out = g;
+    return GMRM_OK;
+}
+
+static int group_create_body(gmrm_group* g, int n, gmrm_ctx** ctxs, gmrm_sampler** smps, int G, int K, int want_rccl) {
     g->n = n; g->G = G; g->K = K;
     g->ctx.assign(ctxs, ctxs + n);
     g->smp.assign(smps, smps + n);
@@ -84,7 +99,7 @@ extern "C" int gmrm_group_create(gmrm_group** out, int n, gmrm_ctx** ctxs, gmrm_
     g->nq = 2 * 4 * ctxs[0]->mbytes;
     bool distinct = true;
     for (int r = 0; r < n; r++) {
-        if (ctxs[r]->N != ctxs[0]->N || ctxs[r]->T != g->T) { delete g; return fail(GMRM_EINVAL, "shards disagree on N or T"); }
+        if (ctxs[r]->N != ctxs[0]->N || ctxs[r]->T != g->T) return fail(GMRM_EINVAL, "shards disagree on N or T");
         for (int s = 0; s < r; s++) if (ctxs[s]->device == ctxs[r]->device) distinct = false;
     }
     g->q.assign(n, nullptr);
@@ -102,7 +117,6 @@ extern "C" int gmrm_group_create(gmrm_group** out, int n, gmrm_ctx** ctxs, gmrm_
         else g->comm.clear();
     }
     if (!g->use_rccl) { g->hq.resize(g->nq); g->hsum.resize(g->nq); }
-    *out = g;
     return GMRM_OK;
 }
 
@@ -110,11 +124,11 @@ extern "C" int gmrm_group_uses_rccl(const gmrm_group* g) { return g && g->use_rc
 
 extern "C" int gmrm_group_destroy(gmrm_group* g) {
     if (!g) return GMRM_OK;
-    for (int r = 0; r < g->n; r++) {
+    for (int r = 0; r < g->n && r < (int)g->ctx.size(); r++) {
         (void)hipSetDevice(g->ctx[r]->device);
-        if (g->use_rccl && g->comm[r]) g->rccl.CommDestroy(g->comm[r]);
-        if (g->q[r]) (void)hipFree(g->q[r]);
-        if (g->st[r]) (void)hipStreamDestroy(g->st[r]);
+        if (g->use_rccl && r < (int)g->comm.size() && g->comm[r]) g->rccl.CommDestroy(g->comm[r]);
+        if (r < (int)g->q.size() && g->q[r]) (void)hipFree(g->q[r]);
+        if (r < (int)g->st.size() && g->st[r]) (void)hipStreamDestroy(g->st[r]);
     }
     if (g->rccl.h) dlclose(g->rccl.h);
     delete g;

@@ -5,21 +5,20 @@
 //   Phenotype::update_epsilon   src/phenotype.cpp:326-393  -> phase C (all workgroups)
 //
 // Layout.  The residual never leaves the chip during a sweep: workgroup w owns SB = 256*R
-// consecutive bytes of every genotype column (4*SB individuals); thread t keeps the residual
-// eps_i of its 4R individuals in VGPRs (for the update).  For the dot products the two exact parts
+// consecutive bytes of every genotype column (4*SB individuals); every thread keeps the residual
+// eps_i of 4R of them in VGPRs (for the update).  For the dot products the two exact parts
 // of every residual (gm_common.h: q1 on the 2^-22 grid, q2 on the 2^-53 grid, both < 2^31 grid
-// units) are ALSO kept in LDS as 31-bit integers cut into four signed base-256 digits and
-// transposed into "planes": one 32-byte record per genotype byte = 4 individuals x 8 digit planes.
+// units) are ALSO kept in LDS as 31-bit integers cut into four signed base-256 digits: eight "digit
+// planes" of one byte per individual.
 //
-// Phase A is marker-per-lane: lane l owns marker l of the batch and walks that marker's slice
-// bytes; one 4-byte LUT read turns a genotype byte into the four 8-bit a-values (the reference's
-// dotp_lut_a row, src/dotp_lut.hpp, as int8), and eight v_dot4c_i32_i8 accumulate them against the
-// eight digit planes.  The planes are the same for all markers: each lane of a 16-lane row loads
-// the record of ONE byte of the current 16-byte chunk and the dot4 reads it through DPP
-// row_newbcast -- no LDS broadcast traffic, no cross-lane reduction, no f64 in the loop.  Integer
-// sums are exact, so the results are bit-identical to the f64 formulation (oracle "canon" mode).
-// The batch's threads split the slice nsub = 256/nbp ways (nbp = batch size rounded up to a power
-// of two); the nsub partial sums per marker meet in LDS through 64-bit integer atomics.
+// Phase A is an int8 contraction on the matrix cores (v_mfma_i32_16x16x64_i8): 16 markers of the
+// batch x 8 digit planes x 64 individuals per instruction, integer accumulation.  The genotype
+// slices sit in the LDS ring RECODED so that a 2-bit field is the reference's dotp_lut_a value
+// (src/dotp_lut.hpp: a = 2, 0, 1, 0 for codes 00, 01, 10, 11) and one v_and per register turns a
+// dword of the ring into an operand register; the missing-genotype layout adds a second pass with
+// the 0/1 indicator of code 01.  Integer sums are exact, so the results are bit-identical to the
+// f64 formulation (oracle "canon" mode).  The four wavefronts split the batch's tiles of 16 markers
+// (and, for small batches, the slice); partial sums meet in LDS through 64-bit integer atomics.
 //
 // Schedule.  The chain is sequential (marker j+1 needs the residual after marker j), and a
 // grid-wide exchange costs microseconds on an 8-XCD part, so markers are processed in
@@ -39,8 +38,9 @@
 // of RPOS column slices in LDS (16-byte chunks XOR-swizzled by position so that 64 lanes reading
 // 64 different slices hit different banks).  Wavefronts 1-3 fetch the slices of upcoming positions
 // as coalesced 16-byte loads during the sampling step (in which they are otherwise idle), hold them
-// in AGPRs and park them in the ring once the sampled batch has released its slots.  (Individuals without a phenotype
-// have residual 0, hence all-zero digit planes: phase A needs no mask; the update applies it.)
+// in AGPRs, and recode + park them in the ring one round later, while wavefront 0 waits for the next
+// totals.  (Individuals without a phenotype have residual 0, hence all-zero digit planes: phase A
+// needs no mask; the update applies it.)
 // Wavefront 3 does the same for the per-marker inputs of the sampling step (marker id, group,
 // previous effect, mave, msig).
 //
@@ -58,6 +58,7 @@
 #include "gm_common.h"
 #include "gm_rng.h"
 #include "gm_internal.h"
+#include <type_traits>
 
 namespace gm {
 
@@ -72,6 +73,7 @@ template <int R> struct Geo {
     static constexpr int PPI = NL / CPP;                  // positions covered by one load instruction
     static constexpr int PFG = 4;                         // loads per wave-uniform branch
     static constexpr int PFN = ((BMAXF + PPI - 1) / PPI + PFG - 1) / PFG * PFG;   // loads per loader thread per round
+    static constexpr int PSTRIDE = 4 * SB + 16;           // bytes per digit plane (one per individual; +16: the planes start on different banks)
     static_assert(NL % CPP == 0 && PPI >= 1, "loader mapping");
     static_assert(2 * BMAXF + 2 <= SW_VMAX && 4 * BMAXG <= SW_VMAX, "exchange rows");
 };
@@ -90,11 +92,9 @@ constexpr int TAB_LDS = 320;                    // group tables up to 320 double
 constexpr int L_TAB  = L_SUM + SW_VMAX * 8;     // double[TAB_LDS] per-group tables
 constexpr int META_POS = 256;                   // per-marker inputs of the sampling step, ring over order positions
 constexpr int L_META = L_TAB + TAB_LDS * 8;     // int m[256], int g[256], double beta[256], mave[256], msig[256]
-constexpr int L_LUTA = L_META + META_POS * 32;  // uint32[256]: a of the 4 genotypes of a byte as 4 x int8
-constexpr int L_LUTB = L_LUTA + 1024;           // uint32[256]: b likewise
-constexpr int L_TOT  = L_LUTB + 1024;           // double[SW_VMAX]: the batch totals as wavefront 0 fetched them
-constexpr int L_PLN  = L_TOT + SW_VMAX * 8;     // uint32[SB][8]: digit planes of the residual
-template <int R> constexpr int l_ring() { return L_PLN + Geo<R>::SB * 32; }
+constexpr int L_TOT  = L_META + META_POS * 32;  // double[SW_VMAX]: the batch totals as wavefront 0 fetched them
+constexpr int L_PLN  = L_TOT + SW_VMAX * 8;     // uint8[8][PSTRIDE]: digit planes of the residual (operand B order)
+template <int R> constexpr int l_ring() { return L_PLN + 8 * Geo<R>::PSTRIDE; }
 static_assert(L_PLN % 16 == 0, "LDS carve");
 // Request > 80 KiB so that exactly one workgroup fits per CU.
 constexpr int L_MIN = 84 * 1024;
@@ -103,7 +103,7 @@ template <int R> constexpr int lds_total() {
 }
 static_assert(lds_total<1>() <= 160 * 1024 && lds_total<2>() <= 160 * 1024 && lds_total<4>() <= 160 * 1024, "LDS budget");
 
-enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD, C_TOTF };
+enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD, C_TOTF, C_RANGE };
 
 size_t sweep_lds_bytes() { return (size_t)lds_total<2>(); }   // the largest of the three carves
 
@@ -181,19 +181,19 @@ __device__ __forceinline__ double reduce2(double a, double b) {
 // would make the loader wavefronts wait here for their in-flight genotype prefetches.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Spin budget shared by every poll loop: give up after ~4 s of wall clock or when another
-// workgroup has raised the abort word.
+// Spin budget shared by every poll loop: give up after `limit` ticks of wall clock (100 MHz;
+// SweepArgs::spin_ticks, 4 s by default) or when another workgroup has raised the abort word.
 struct Spin {
-    unsigned long long t0;
+    unsigned long long t0, limit;
     unsigned n;
-    __device__ __forceinline__ void start() { t0 = __builtin_amdgcn_s_memrealtime(); n = 0; }
+    __device__ __forceinline__ void start(unsigned long long lim) { t0 = __builtin_amdgcn_s_memrealtime(); limit = lim; n = 0; }
     __device__ __forceinline__ bool expired(unsigned* abort_word) {
 #ifndef GM_POLL_SLEEP
 #define GM_POLL_SLEEP 1
 #endif
         __builtin_amdgcn_s_sleep(GM_POLL_SLEEP);
         if ((++n & 63u) != 0u) return false;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull || ld_u32(abort_word) != 0u) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit || ld_u32(abort_word) != 0u) {
             st_u32(abort_word, 1u);
             return true;
         }
@@ -435,10 +435,12 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
                 upd = 1;
                 const double bs_ = dbeta * in.msig;
                 const double mdb = -in.mave;
-                s_val[0] = (mdb * 1.0 + 2.0) * bs_;
-                s_val[1] = (mdb * 0.0 + 0.0) * bs_;
-                s_val[2] = (mdb * 1.0 + 1.0) * bs_;
-                s_val[3] = (mdb * 1.0 + 0.0) * bs_;
+                // (mdb * b + a) * bs_ per genotype, indexed by the RING code c' (k_sweep, phase A): c' = 2, 3, 1, 0
+                // for .bed codes 00, 01, 10, 11 with (a, b) = (2,1), (0,0), (1,1), (0,1) (src/dotp_lut.hpp)
+                s_val[2] = (mdb * 1.0 + 2.0) * bs_;
+                s_val[3] = (mdb * 0.0 + 0.0) * bs_;
+                s_val[1] = (mdb * 1.0 + 1.0) * bs_;
+                s_val[0] = (mdb * 1.0 + 0.0) * bs_;
             }
             if (writer) {
                 out.acum[m] = acum_v; out.betas_out[m] = beta_new; out.comp[m] = kc;
@@ -487,12 +489,12 @@ __device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, c
 // polling), parks them in LDS and lane j picks the values of batch positions j and 64 + j.
 // Returns false on timeout.
 __device__ __forceinline__ bool poll_totals(int nb, bool fast, const unsigned long long* Ttg, unsigned tag, char* smem,
-                                            Totals& tot0, Totals& tot1, unsigned* abort_word) {
+                                            Totals& tot0, Totals& tot1, unsigned* abort_word, unsigned long long spin_limit) {
     const int lane = threadIdx.x & 63;
     double* s_tot = reinterpret_cast<double*>(smem + L_TOT);
     const int nv = fast ? 2 * nb + 2 : 4 * nb;
     Spin sp;
-    sp.start();
+    sp.start(spin_limit);
     bool bad = false;
     u32x4 d[4];
     for (;;) {
@@ -519,12 +521,6 @@ __device__ __forceinline__ bool poll_totals(int nb, bool fast, const unsigned lo
     return !__any(bad);
 }
 
-// ---- per-R storage types ------------------------------------------------------------------
-template <int R> struct Slice;
-template <> struct Slice<1> { using own_t = uint8_t; };
-template <> struct Slice<2> { using own_t = uint16_t; };
-template <> struct Slice<4> { using own_t = uint32_t; };
-
 // Diagnostic build only (-DGM_SWEEP_PROF): thread 0 of every workgroup accumulates wall-clock
 // ticks (100 MHz) per phase; workgroups 0 and W/2 write them to stats[4..]/stats[12..].
 #ifdef GM_SWEEP_PROF
@@ -544,34 +540,20 @@ template <> struct Slice<4> { using own_t = uint32_t; };
 #endif
 
 // ---- phase A building blocks --------------------------------------------------------------
-// Eight dot4 of one genotype byte's a-values (4 x int8) against the digit-plane record that lane
-// J of this 16-lane row holds (DPP row_newbcast).  All lanes of the row must be active.
-#define GM_DOT8(J, A4, ACC, PA, PB)                                                                   \
-    asm volatile("v_dot4c_i32_i8_dpp %0, %8, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"  \
-                 "v_dot4c_i32_i8_dpp %1, %9, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t"  \
-                 "v_dot4c_i32_i8_dpp %2, %10, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
-                 "v_dot4c_i32_i8_dpp %3, %11, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
-                 "v_dot4c_i32_i8_dpp %4, %12, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
-                 "v_dot4c_i32_i8_dpp %5, %13, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
-                 "v_dot4c_i32_i8_dpp %6, %14, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n\t" \
-                 "v_dot4c_i32_i8_dpp %7, %15, %16 row_newbcast:" #J " row_mask:0xf bank_mask:0xf"     \
-                 : "+v"(ACC[0]), "+v"(ACC[1]), "+v"(ACC[2]), "+v"(ACC[3]),                            \
-                   "+v"(ACC[4]), "+v"(ACC[5]), "+v"(ACC[6]), "+v"(ACC[7])                             \
-                 : "v"(PA.x), "v"(PA.y), "v"(PA.z), "v"(PA.w), "v"(PB.x), "v"(PB.y), "v"(PB.z), "v"(PB.w), "v"(A4) \
-                 : "memory")   /* volatile + memory: the LDS reads written before a block stay before it */
+// Phase A is an int8 contraction on the matrix cores: out[marker][plane] = sum_i a_i(marker) * digit_i[plane]
+// with v_mfma_i32_16x16x64_i8 (16 markers x 16 columns x 64 individuals per instruction; columns 0..7 are
+// the eight digit planes).  Operand A must be int8 per individual; expanding 2-bit codes is the cost, so
+// the ring holds RECODED genotypes c' whose 2-bit field IS the reference's dotp_lut_a value:
+//     .bed code 00 (a=2,b=1) -> 10    01 (missing, a=b=0) -> 11    10 (a=1,b=1) -> 01    11 (a=0,b=1) -> 00
+// and one v_and per register isolates field i of the four bytes of a dword (value a * 4^i; the factor is
+// divided out of that field's own accumulator afterwards; the top field is shifted down first).  A lane
+// (marker m = lane & 15, kg = lane >> 4) reads ONE 16-byte chunk (64 individuals) per super-step and feeds
+// four MFMAs, MFMA i taking field i of each dword.  Operand B therefore holds the digit planes in the
+// matching order: position 16 i + 4 j + b of a chunk <- individual 16 j + 4 b + i (dword j, byte b, field i).
+typedef int v4i __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ uint32_t chunk_byte(const uint4& w, int j) {      // byte j (0..15) of a 16-byte chunk
-    const uint32_t ww = j < 4 ? w.x : (j < 8 ? w.y : (j < 12 ? w.z : w.w));
-    return (ww >> (8 * (j & 3))) & 0xffu;
-}
-// 4 * (byte k of w) in ONE VALU operation: v_lshlrev_b32 with an SDWA byte select on the shifted operand
-__device__ __forceinline__ uint32_t lut_offset(uint32_t w, int k, uint32_t two) {
-    uint32_t r;
-    if (k == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(two), "v"(w));
-    else if (k == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(two), "v"(w));
-    else if (k == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(two), "v"(w));
-    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(two), "v"(w));
-    return r;
+__device__ __forceinline__ uint32_t recode_codes(uint32_t w) {
+    return (~w & 0xAAAAAAAAu) | ((w ^ (w >> 1)) & 0x55555555u);
 }
 // four signed base-256 digits of x (|x| <= 2^30) as the four bytes of the result
 __device__ __forceinline__ uint32_t signed_digits(int x) { return ((uint32_t)x + 0x00808080u) ^ 0x00808080u; }
@@ -588,15 +570,53 @@ __device__ __forceinline__ uint4 digit_planes(uint32_t z0, uint32_t z1, uint32_t
     r.w = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);               // b3
     return r;
 }
+// sum of x over the four lanes of a quad (both halves of a 64-bit integer through DPP quad_perm)
+__device__ __forceinline__ long long quad_sum64(long long x) {
+    int lo = (int)x, hi = (int)(x >> 32);
+    long long y = x + (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, hi, DPP_QUAD_1032, 0xf, 0xf, false) << 32) |
+                                  (unsigned)__builtin_amdgcn_update_dpp(0, lo, DPP_QUAD_1032, 0xf, 0xf, false));
+    lo = (int)y; hi = (int)(y >> 32);
+    y = y + (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false) << 32) |
+                        (unsigned)__builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false));
+    return y;
+}
+
+// One super-step's LDS operands: the lane's 16-byte chunk of its marker's slice (operand A before the
+// field masks) and the 64 bytes of its digit plane (operand B of the four MFMAs).  The reads are inline
+// asm so that they can be issued a whole super-step ahead of their use: hipcc does not count them, the
+// matching stage_wait<N> does (N = LDS reads issued after this stage's; LDS returns in order).
+struct Stage { u32x4 w; v4i b0, b1, b2, b3; };   // native vector types: "+v" operands must be registers
+__device__ __forceinline__ Stage stage_read(uint32_t waddr, uint32_t baddr) {
+    u32x4 w; v4i b0, b1, b2, b3;
+    asm volatile("ds_read_b128 %0, %5\n\t"
+                 "ds_read_b128 %1, %6\n\t"
+                 "ds_read_b128 %2, %6 offset:16\n\t"
+                 "ds_read_b128 %3, %6 offset:32\n\t"
+                 "ds_read_b128 %4, %6 offset:48"
+                 : "=&v"(w), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(waddr), "v"(baddr) : "memory");
+    return Stage{w, b0, b1, b2, b3};
+}
+template <int N> __device__ __forceinline__ Stage stage_wait(const Stage st) {
+    static_assert(N == 0 || N == 5, "reads of one later stage, or none");
+    u32x4 w = st.w; v4i b0 = st.b0, b1 = st.b1, b2 = st.b2, b3 = st.b3;
+    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(w), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : : "memory");
+    return Stage{w, b0, b1, b2, b3};
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
 
 template <int R, bool FAST>
 __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using own_t = typename Slice<R>::own_t;          // this thread's R bytes of a column
     using GE = Geo<R>;
     constexpr int NI = 4 * R;                        // individuals per thread
+    constexpr int ND = NI / 4;                       // dwords of a column slice a thread takes its genotypes from
     constexpr int SB = GE::SB, CPP = GE::CPP, RPOS = GE::RPOS, PPI = GE::PPI, PFN = GE::PFN, PFG = GE::PFG;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x;
+    constexpr int SS = CPP / 4;                      // super-steps: 4 chunks = 256 individuals, one chunk per lane group
+    constexpr int PST = GE::PSTRIDE;                 // bytes per digit plane
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wg = blockIdx.x;
     const int W = a.W, K = a.K, G = a.G;
     constexpr bool fast = FAST;                      // exchange layout, fixed per launch (host: all_nomiss)
     const int BMAX = fast ? GE::BMAXF : GE::BMAXG;
@@ -610,33 +630,19 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     double* s_red = reinterpret_cast<double*>(smem + L_RED);
     double* s_wsq = reinterpret_cast<double*>(smem + L_WSQ);
     double* s_tab = reinterpret_cast<double*>(smem + L_TAB);
-    uint32_t* lut_a = reinterpret_cast<uint32_t*>(smem + L_LUTA);
-    uint32_t* lut_b = reinterpret_cast<uint32_t*>(smem + L_LUTB);
     char* planes = smem + L_PLN;
     const bool tab_in_lds = G * (1 + 3 * K) <= TAB_LDS;
     const double* tabp = tab_in_lds ? s_tab : a.sigmag;   // sigmag|denom|logpi|mhl, contiguous
     char* ring = smem + l_ring<R>();
     unsigned* abort_word = a.cnt + 64;
+    const unsigned long long spin_limit = a.spin_ticks;
     unsigned long long* Pg = reinterpret_cast<unsigned long long*>(a.P);
     unsigned long long* Ttg = reinterpret_cast<unsigned long long*>(a.Tt);
 
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) {   // phase A addresses the tables absolutely
-        if (tid == 0) atomicMax(a.err, 3);
-        return;
-    }
     for (int i = tid; i < 624; i += SW_TPB) s_rng0[i] = a.rng_state[i];
     for (int i = tid; i < G * K; i += SW_TPB) s_cass[i] = 0;
     if (tab_in_lds)
         for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];
-    {   // the reference's dotp_lut_a / dotp_lut_b rows (src/dotp_lut.hpp) as 4 x int8 per genotype byte
-        uint32_t wa = 0, wb = 0;
-        for (int j = 0; j < 4; j++) {
-            const int c = (tid >> (2 * j)) & 3;
-            wa |= (uint32_t)code_a(c) << (8 * j);
-            wb |= (uint32_t)code_b(c) << (8 * j);
-        }
-        lut_a[tid] = wa; lut_b[tid] = wb;
-    }
     s_sum[tid] = 0ull;
 #ifdef GM_SWEEP_PROF
     if (tid < 8) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[tid] = 0ull;
@@ -646,57 +652,71 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         ctl[C_RNGERR] = 0;
         ctl[C_BAD] = 0;
         ctl[C_TOTF] = 0;
+        ctl[C_RANGE] = 0;
         ctl[C_EMA] = 16 * a.batch_init / 2;
         ctl[C_NBNEXT] = a.batch_init < 16 ? 16 : (a.batch_init > BMAX ? BMAX : a.batch_init);
     }
     __syncthreads();
     block_advance(s_rng0, s_rng1, ctl, false);       // S1 = twist(S0)
 
-    // ---- this thread's slice of the residual ------------------------------------------
-    const size_t b0 = ((size_t)wg * SW_TPB + tid) * R;
-    const bool valid = b0 < a.stride;
+    // ---- this thread's individuals -----------------------------------------------------
+    // The workgroup's 4*SB individuals are numbered by POSITION in operand B's order (header of this
+    // section): position = 64 chunk + 16 field + 4 dword + byte.  Thread t owns positions [t*NI, t*NI + NI):
+    // one 2-bit field (o_fld) of NI consecutive bytes (from byte o_jb) of one 16-byte chunk (o_chunk), so
+    // its digit-plane bytes are contiguous and its genotypes sit in ND dwords of a column slice.
+    const int p0w = tid * NI;
+    const int o_chunk = p0w >> 6, o_fld = (p0w >> 4) & 3, o_jb = p0w & 15;
+    const size_t o_byte = (size_t)wg * SB + (size_t)o_chunk * 16 + (size_t)o_jb;   // first of the NI column bytes
+    const bool valid = o_byte < a.stride;                   // stride is a multiple of 16: a chunk is inside or outside
     double eps[NI];
-    if (valid) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) eps[i] = a.eps[4 * b0 + i];
-    } else {
+    for (int q = 0; q < NI; q++) eps[q] = valid ? a.eps[4 * (o_byte + (size_t)q) + (size_t)o_fld] : 0.0;
+    // NA / out-of-range individuals: their residual is 0 and stays 0, so their digit planes are 0 and
+    // phase A may see ANY genotype code for them; only the residual update has to skip them: the owner
+    // thread forces their ring codes to 11 (missing, update value 0) when it reads its bytes in phase C.
+    uint32_t na_or[ND];
 #pragma unroll
-        for (int i = 0; i < NI; i++) eps[i] = 0.0;
+    for (int d = 0; d < ND; d++) {
+        const uint32_t nam = valid ? *reinterpret_cast<const uint32_t*>(a.namask2 + o_byte + 4 * d) : 0u;
+        na_or[d] = ~nam & (0x03030303u << (2 * o_fld));
     }
     // split the thread's residuals, park their digit planes in LDS, leave the wavefront's sum of
     // q1 / q2 in s_wsq (readers: after the next barrier)
     auto refresh_planes = [&]() {
         double sq1 = 0.0, sq2 = 0.0;
+        bool big = false;
+        uint32_t pl[8][ND];
 #pragma unroll
-        for (int k = 0; k < R; k++) {
+        for (int g4 = 0; g4 < ND; g4++) {
             uint32_t z1[4], z2[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                const double x = eps[4 * g4 + j];
+                big |= !(fabs(x) < EPS_ABS_LIMIT);               // the digits below need |x| < 2^8 (also catches NaN)
                 double q1, q2;
-                split2(eps[4 * k + j], q1, q2);
+                split2(x, q1, q2);
                 sq1 += q1; sq2 += q2;
                 z1[j] = signed_digits((int)(q1 * 0x1p22));      // exact: q1 is a multiple of 2^-22, |q1| <= 2^8
                 z2[j] = signed_digits((int)(q2 * 0x1p53));      // exact: q2 is a multiple of 2^-53, |q2| <= 2^-23
             }
-            uint4* rec = reinterpret_cast<uint4*>(planes + ((size_t)tid * R + k) * 32);
-            rec[0] = digit_planes(z1[0], z1[1], z1[2], z1[3]);
-            rec[1] = digit_planes(z2[0], z2[1], z2[2], z2[3]);
+            const uint4 d1 = digit_planes(z1[0], z1[1], z1[2], z1[3]);
+            const uint4 d2 = digit_planes(z2[0], z2[1], z2[2], z2[3]);
+            pl[0][g4] = d1.x; pl[1][g4] = d1.y; pl[2][g4] = d1.z; pl[3][g4] = d1.w;
+            pl[4][g4] = d2.x; pl[5][g4] = d2.y; pl[6][g4] = d2.z; pl[7][g4] = d2.w;
         }
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+            char* dst = planes + n * PST + p0w;
+            if constexpr (ND == 1) *reinterpret_cast<uint32_t*>(dst) = pl[n][0];
+            else if constexpr (ND == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pl[n][0], pl[n][1]);
+            else *reinterpret_cast<uint4*>(dst) = make_uint4(pl[n][0], pl[n][1], pl[n][2], pl[n][3]);
+        }
+        if (big) ctl[C_RANGE] = 1;                               // reported as error 4; every workgroup leaves
         const double r2 = reduce2(sq1, sq2);
         if (lane == 0) s_wsq[wave * 2 + 0] = r2;
         if (lane == 32) s_wsq[wave * 2 + 1] = r2;
     };
     refresh_planes();
-
-    // NA / out-of-range individuals: their residual is 0 and stays 0, so their digit planes are 0 and
-    // phase A may see ANY genotype code for them; only the residual update has to skip them.  The
-    // owner thread forces their codes to 01 (update value 0) when it reads its bytes in phase C.
-    own_t own_keep = 0, own_force = (own_t)0x55555555u;
-    if (valid) {
-        const own_t nam = *reinterpret_cast<const own_t*>(a.namask2 + b0);
-        own_keep = nam;
-        own_force = (own_t)(~nam) & (own_t)0x55555555u;
-    }
 
     // ---- loader role (wavefronts 1-3): one 16-byte chunk of PFN upcoming columns per round -----
     const bool loader = wave != 0;                    // wavefront 0 polls: its loads must not queue behind prefetches
@@ -713,7 +733,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         return reinterpret_cast<uint4*>(ring + (size_t)((unsigned)p % (unsigned)RPOS) * SB + 16 * (chunk ^ (p & (CPP - 1))));
     };
     u32x4 pf[PFN];                                    // in flight / parked in AGPRs (inline asm below owns them)
-    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)ring;   // LDS byte offset of the ring
     int pos = 0;
     int hi = 0;                                       // ring holds order positions [pos, hi)
     int npf = 0;                                      // positions [hi, hi + npf) are in flight / in registers
@@ -723,7 +742,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (loader) {
 #pragma unroll 1
             for (int p = from + lpj; p < to; p += PPI) {
-                const uint4 v = *reinterpret_cast<const uint4*>(a.bed + (size_t)a.order[p] * a.stride + cb);
+                uint4 v = *reinterpret_cast<const uint4*>(a.bed + (size_t)a.order[p] * a.stride + cb);
+                v.x = recode_codes(v.x); v.y = recode_codes(v.y); v.z = recode_codes(v.z); v.w = recode_codes(v.w);
                 *ring_chunk(p, lci) = v;
             }
         }
@@ -757,13 +777,13 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             // the marker ids above (L2 hits) are in flight meanwhile.
             if (gate_tag != 0u) {
                 Spin sp;
-                sp.start();
+                sp.start(spin_limit);
                 while (*reinterpret_cast<const volatile int*>(&ctl[C_TOTF]) != (int)gate_tag)
                     if (sp.expired(abort_word)) break;
             }
-            // The column loads and their ring writes are inline asm on AGPR operands: the data never
-            // passes through compiler-managed registers (which would cost a wait per load), and the
-            // only wait is the explicit one in prefetch_commit, a whole sampling step later.
+            // The column loads are inline asm on AGPR destinations: the compiler neither waits for them nor
+            // counts them; the only wait is the explicit one in prefetch_commit, a whole round later
+            // (tools/check_prefetch_regs.py checks in the disassembly that nothing touches them in between).
 #pragma unroll
             for (int c8 = 0; c8 < PFN; c8 += PFG) {
                 if (c8 * PPI < npf) {
@@ -776,15 +796,16 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             }
         }
     };
-    // park the requested slices in the ring as far as the window [pos, pos + RPOS) allows (the rest
-    // is dropped and requested again); readers see them after the next barrier.  Called a full
-    // round after the issue, so nobody waits for HBM.
+    // recode the requested slices and park them in the ring as far as the window [pos, pos + RPOS) allows
+    // (the rest is dropped and requested again); readers see them after the next barrier.  Called a full
+    // round after the issue -- while wavefront 0 waits for the totals, the loader wavefronts have nothing
+    // else to do -- so nobody waits for HBM and the recoding is off the critical path.
     auto prefetch_commit = [&]() {
         int nc = pos + RPOS - hi;
         if (nc > npf) nc = npf;
         if (nc < 0) nc = 0;
-        if (loader) {
-            if (nc > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (loader && nc > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // slot of this thread's first position; later ones are PPI apart (one conditional wrap each)
             const int p_first = hi + lpj;
             const int s_first = (int)((unsigned)p_first % (unsigned)RPOS);
@@ -793,11 +814,15 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 if (c8 * PPI < nc) {
 #pragma unroll
                     for (int i = c8; i < c8 + PFG; i++) {
+                        asm volatile("" : "+a"(pf[i]));     // the value is defined HERE, after the wait: no use of it can be scheduled earlier
                         const int o = i * PPI + lpj;
                         int sl = s_first + i * PPI;
                         sl = sl >= RPOS ? sl - RPOS : sl;
-                        const uint32_t dst = ring_lds + (uint32_t)sl * SB + 16u * (uint32_t)(lci ^ ((p_first + i * PPI) & (CPP - 1)));
-                        if (o < nc) asm volatile("ds_write_b128 %0, %1" : : "v"(dst), "a"(pf[i]) : "memory");
+                        if (o < nc) {
+                            uint4 v;
+                            v.x = recode_codes(pf[i].x); v.y = recode_codes(pf[i].y); v.z = recode_codes(pf[i].z); v.w = recode_codes(pf[i].w);
+                            *reinterpret_cast<uint4*>(ring + (size_t)sl * SB + 16 * (lci ^ ((p_first + i * PPI) & (CPP - 1)))) = v;
+                        }
                     }
                 }
             }
@@ -906,72 +931,91 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             li1.m = mr_m[sl]; li1.g = mr_g[sl]; li1.beta_old = mr_beta[sl]; li1.mave = mr_mave[sl]; li1.msig = mr_msig[sl];
         }
         max_nb = nb > max_nb ? nb : max_nb;
-        // thread -> (marker mk of the batch, sub-slice sub): nbp = batch size rounded up to a power of two >= 16
-        int lg = 4;
-        while ((1 << lg) < nb) lg++;
-        const int nbp = 1 << lg;
-        const int mk = tid & (nbp - 1), sub = tid >> lg;
-        const int nch = (CPP << lg) / SW_TPB;          // 16-byte chunks per thread (>= 1)
-        const int pl = p0 + (mk < nb ? mk : nb - 1);   // idle lanes shadow the last marker (their sums are dropped)
-        const char* slice = ring + (size_t)((unsigned)pl % (unsigned)RPOS) * SB;
-        const int swz = pl & (CPP - 1);
-        const char* prec = planes + ((size_t)sub * nch * 16 + (lane & 15)) * 32;
-        int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int bcc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        // Software pipeline over the thread's 16-byte chunks, two register stages used in turn (no copies).
-        // While the 128 dot4 of one stage run, the other stage is filled one table read per 8 dot4 (the
-        // LGKM counter tracks 15 operations: a burst of 19 reads in front of the dot4 would stall them,
-        // and four wavefronts bursting together would queue on the LDS), its plane record first, the
-        // genotype bytes of the chunk after it half-way through.
-        auto chunk_at = [&](int c) { return *reinterpret_cast<const uint4*>(slice + 16 * ((sub * nch + (c < nch ? c : nch - 1)) ^ swz)); };
-        auto rec_at = [&](int c, int half) { return *reinterpret_cast<const uint4*>(prec + (size_t)(c < nch ? c : nch - 1) * 512 + 16 * half); };
-        struct Stage { uint4 pa, pb; uint32_t a4[16], b4[16]; };
-        const uint32_t two = 2u;
-        // absolute LDS addresses (the dynamic LDS block starts at 0, checked at kernel entry): the table
-        // base goes into the instruction's offset field instead of a VALU add per byte
-#define GM_LUT(S, W, J) { const uint32_t off_ = lut_offset((J) < 4 ? W.x : ((J) < 8 ? W.y : ((J) < 12 ? W.z : W.w)), (J) & 3, two);   \
-            S.a4[J] = *(const __attribute__((address_space(3))) uint32_t*)(off_ + (uint32_t)L_LUTA);                                   \
-            if (!FAST) S.b4[J] = *(const __attribute__((address_space(3))) uint32_t*)(off_ + (uint32_t)L_LUTB); }
-#define GM_STEP(CUR, NXT, WN, J) { GM_LUT(NXT, WN, J) GM_DOT8(J, CUR.a4[J], acc, CUR.pa, CUR.pb); if (!FAST) { GM_DOT8(J, CUR.b4[J], bcc, CUR.pa, CUR.pb); } }
-        // dots of stage CUR; fill stage NXT from the bytes WN (chunk CN); fetch the bytes of chunk CN + 1 into WF
-#define GM_RUN(CUR, NXT, WN, CN, WF) {                                                                          \
-            NXT.pa = rec_at(CN, 0); NXT.pb = rec_at(CN, 1);                                                      \
-            asm volatile("s_nop 1" ::: "memory");   /* VALU write -> DPP read of a plane register: 2 wait states */ \
-            GM_STEP(CUR, NXT, WN, 0) GM_STEP(CUR, NXT, WN, 1) GM_STEP(CUR, NXT, WN, 2) GM_STEP(CUR, NXT, WN, 3)      \
-            GM_STEP(CUR, NXT, WN, 4) GM_STEP(CUR, NXT, WN, 5) GM_STEP(CUR, NXT, WN, 6) GM_STEP(CUR, NXT, WN, 7)      \
-            WF = chunk_at((CN) + 1);                                                                             \
-            GM_STEP(CUR, NXT, WN, 8) GM_STEP(CUR, NXT, WN, 9) GM_STEP(CUR, NXT, WN, 10) GM_STEP(CUR, NXT, WN, 11)    \
-            GM_STEP(CUR, NXT, WN, 12) GM_STEP(CUR, NXT, WN, 13) GM_STEP(CUR, NXT, WN, 14) GM_STEP(CUR, NXT, WN, 15) }
-        Stage sa, sb;
-        uint4 wa = chunk_at(0), wb = chunk_at(1);
-        sa.pa = rec_at(0, 0); sa.pb = rec_at(0, 1);
-        GM_LUT(sa, wa, 0) GM_LUT(sa, wa, 1) GM_LUT(sa, wa, 2) GM_LUT(sa, wa, 3) GM_LUT(sa, wa, 4) GM_LUT(sa, wa, 5) GM_LUT(sa, wa, 6) GM_LUT(sa, wa, 7)
-        GM_LUT(sa, wa, 8) GM_LUT(sa, wa, 9) GM_LUT(sa, wa, 10) GM_LUT(sa, wa, 11) GM_LUT(sa, wa, 12) GM_LUT(sa, wa, 13) GM_LUT(sa, wa, 14) GM_LUT(sa, wa, 15)
-        for (int c = 0; c < nch; c += 2) {
-            GM_RUN(sa, sb, wb, c + 1, wa)
-            if (c + 1 < nch) {                        // wave-uniform (nch is 1 or even)
-                GM_RUN(sb, sa, wa, c + 2, wb)
+        // work split: nt tiles of 16 markers; the 4 wavefronts = tsplit tile groups x ksplit parts of the slice
+        const int nt = (nb + 15) >> 4;
+        const int tsplit = nt >= 4 ? 4 : (nt >= 2 ? 2 : 1);
+        const int ksplit = 4 / tsplit;
+        const int wt = wave & (tsplit - 1), wk = wave / tsplit;
+        const int ss_lo = wk * (SS / ksplit);               // first super-step of this wavefront's part of the slice
+        const int mrow = lane & 15, kg = lane >> 4;
+        const char* pbase = planes + (lane & 7) * PST + kg * 64;      // columns 8..15 of B repeat 0..7 (their results are dropped)
+        constexpr uint32_t M0 = 0x03030303u, M1 = 0x01010101u;
+        // One tile = 16 markers x NS super-steps of the slice starting at ss_lo.  NS is a compile-time count so
+        // that the body is ONE basic block: the LDS reads of later super-steps are issued ahead of the MFMAs
+        // of earlier ones (a wave-uniform test per super-step would serialise read -> wait -> MFMA).
+        auto tile_pass = [&](auto ns_tag, int t) {
+            constexpr int NS = decltype(ns_tag)::value;
+            const int mk = 16 * t + mrow;
+            const int pl = p0 + (mk < nb ? mk : nb - 1);              // idle rows shadow the last marker (their sums are dropped)
+            const char* slice = ring + (size_t)((unsigned)pl % (unsigned)RPOS) * SB;
+            const int swz = pl & (CPP - 1);
+            const uint32_t pb0 = lds_addr(pbase) + (uint32_t)ss_lo * 256u;
+            const uint32_t sl0 = lds_addr(slice);
+            v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+            v4i zcc0 = {0, 0, 0, 0}, zcc1 = {0, 0, 0, 0}, zcc2 = {0, 0, 0, 0};     // general layout: the missing-genotype indicator
+            Stage stg[2];
+            stg[0] = stage_read(sl0 + 16u * (uint32_t)((4 * ss_lo + kg) ^ swz), pb0);
+#pragma unroll
+            for (int s = 0; s < NS; s++) {
+                if (s + 1 < NS) {                     // the next super-step's reads are in flight during this one's arithmetic
+                    stg[(s + 1) & 1] = stage_read(sl0 + 16u * (uint32_t)((4 * (ss_lo + s + 1) + kg) ^ swz), pb0 + (uint32_t)(s + 1) * 256u);
+                    stg[s & 1] = stage_wait<5>(stg[s & 1]);
+                } else {
+                    stg[s & 1] = stage_wait<0>(stg[s & 1]);
+                }
+                const u32x4 w = stg[s & 1].w;
+                const v4i b0 = stg[s & 1].b0, b1 = stg[s & 1].b1, b2 = stg[s & 1].b2, b3 = stg[s & 1].b3;
+                const v4i a0 = {(int)(w.x & M0), (int)(w.y & M0), (int)(w.z & M0), (int)(w.w & M0)};
+                const v4i a1 = {(int)(w.x & (M0 << 2)), (int)(w.y & (M0 << 2)), (int)(w.z & (M0 << 2)), (int)(w.w & (M0 << 2))};
+                const v4i a2 = {(int)(w.x & (M0 << 4)), (int)(w.y & (M0 << 4)), (int)(w.z & (M0 << 4)), (int)(w.w & (M0 << 4))};
+                const v4i a3 = {(int)((w.x >> 6) & M0), (int)((w.y >> 6) & M0), (int)((w.z >> 6) & M0), (int)((w.w >> 6) & M0)};
+                acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc2, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, b3, acc0, 0, 0, 0);
+                if (!FAST) {
+                    // 1 in the low bit of every field that reads 11 (missing): field & (field >> 1)
+                    const uint4 u = make_uint4(w.x & (w.x >> 1), w.y & (w.y >> 1), w.z & (w.z >> 1), w.w & (w.w >> 1));
+                    const v4i z0 = {(int)(u.x & M1), (int)(u.y & M1), (int)(u.z & M1), (int)(u.w & M1)};
+                    const v4i z1 = {(int)(u.x & (M1 << 2)), (int)(u.y & (M1 << 2)), (int)(u.z & (M1 << 2)), (int)(u.w & (M1 << 2))};
+                    const v4i z2 = {(int)(u.x & (M1 << 4)), (int)(u.y & (M1 << 4)), (int)(u.z & (M1 << 4)), (int)(u.w & (M1 << 4))};
+                    const v4i z3 = {(int)((u.x >> 6) & M1), (int)((u.y >> 6) & M1), (int)((u.z >> 6) & M1), (int)((u.w >> 6) & M1)};
+                    zcc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(z0, b0, zcc0, 0, 0, 0);
+                    zcc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(z1, b1, zcc1, 0, 0, 0);
+                    zcc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(z2, b2, zcc2, 0, 0, 0);
+                    zcc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(z3, b3, zcc0, 0, 0, 0);
+                }
             }
-        }
-#undef GM_RUN
-#undef GM_STEP
-#undef GM_LUT
-        if (mk < nb) {                                // digits -> 64-bit sums; sub-slices meet in LDS (integer: exact, any order)
-            const long long s1 = (long long)acc[0] + ((long long)acc[1] << 8) + ((long long)acc[2] << 16) + ((long long)acc[3] << 24);
-            const long long s2 = (long long)acc[4] + ((long long)acc[5] << 8) + ((long long)acc[6] << 16) + ((long long)acc[7] << 24);
-            if (fast) {
-                atomicAdd(&s_sum[2 * mk + 0], (unsigned long long)s1);
-                atomicAdd(&s_sum[2 * mk + 1], (unsigned long long)s2);
-            } else {
-                const long long u1 = (long long)bcc[0] + ((long long)bcc[1] << 8) + ((long long)bcc[2] << 16) + ((long long)bcc[3] << 24);
-                const long long u2 = (long long)bcc[4] + ((long long)bcc[5] << 8) + ((long long)bcc[6] << 16) + ((long long)bcc[7] << 24);
-                atomicAdd(&s_sum[4 * mk + 0], (unsigned long long)s1);
-                atomicAdd(&s_sum[4 * mk + 1], (unsigned long long)s2);
-                atomicAdd(&s_sum[4 * mk + 2], (unsigned long long)u1);
-                atomicAdd(&s_sum[4 * mk + 3], (unsigned long long)u2);
+            // C: column n = lane & 15 (digit plane), rows 4 kg + r (marker of the tile).  The four planes of
+            // one exact part meet in a quad: sum_p digit_p * 256^p as a 64-bit integer; the parts of the slice
+            // (ksplit wavefronts) meet in LDS (integer: exact, any order).
+            const int n = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = 16 * t + 4 * kg + r;
+                const int x = acc0[r] + (acc1[r] >> 2) + (acc2[r] >> 4);          // sum c' * digit (c' = a wherever the residual is not 0)
+                const long long sx = quad_sum64((long long)x << (8 * (n & 3)));
+                if (FAST) {
+                    if ((n & 3) == 0 && n < 8 && m < nb) atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)sx);
+                } else {
+                    // a = c' - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
+                    // slice's sum of d is added at the publish
+                    const int z = zcc0[r] + (zcc1[r] >> 2) + (zcc2[r] >> 4);
+                    const long long sz = quad_sum64((long long)z << (8 * (n & 3)));
+                    if ((n & 3) == 0 && n < 8 && m < nb) {
+                        atomicAdd(&s_sum[4 * m + (n >> 2)], (unsigned long long)(sx - 3 * sz));
+                        atomicAdd(&s_sum[4 * m + 2 + (n >> 2)], (unsigned long long)(-sz));
+                    }
+                }
             }
+        };
+#pragma unroll 1
+        for (int t = wt; t < nt; t += tsplit) {
+            if (ksplit == 1) tile_pass(std::integral_constant<int, SS>{}, t);
+            else if (ksplit == 2) tile_pass(std::integral_constant<int, SS / 2>{}, t);
+            else tile_pass(std::integral_constant<int, SS / 4>{}, t);
         }
-        __syncthreads();
+        lds_barrier();                                // the LDS sums are complete (prefetches stay in flight)
         const int nv = fast ? 2 * nb + 2 : 4 * nb;
         if (tid < nv) {
             double tot;
@@ -979,8 +1023,14 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 const int w2 = tid - 2 * nb;
                 tot = s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2];
             } else {
+                long long v = (long long)s_sum[tid];
+                if (!fast && (tid & 2)) {             // sum b d = sum d - Z: this slice's sum of the exact part, as an integer
+                    const int w2 = tid & 1;
+                    const double dsum = s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2];
+                    v += (long long)(dsum * (w2 ? 0x1p53 : 0x1p22));                // exact: a multiple of the grid, < 2^53 units
+                }
                 // |sum| < 2^53 grid units: the conversion and the power-of-two scaling are exact
-                tot = (double)(long long)s_sum[tid] * ((tid & 1) ? 0x1p-53 : 0x1p-22);
+                tot = (double)v * ((tid & 1) ? 0x1p-53 : 0x1p-22);
                 s_sum[tid] = 0ull;
             }
             put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)tid * a.Wpad + wg), b.gen + 1u, tot);
@@ -998,7 +1048,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 double x = 0.0;
                 if (tid < W) {
                     Spin sp;
-                    sp.start();
+                    sp.start(spin_limit);
                     const unsigned long long* gp = Pb + 2 * ((size_t)v * a.Wpad + tid);
                     while (!get_value(gp, b.gen + 1u, x)) {
                         if (sp.expired(abort_word)) { bad = true; x = 0.0; break; }
@@ -1065,9 +1115,13 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
         have_next = do_compute;
         if (have_next) nxt = tb;
-        // request the slices / sampling inputs the ring can take once the current batch has been
-        // walked to its end; wavefronts 1-3 idle through the sampling step below, which hides the
-        // marker-id round trip and most of the HBM latency
+        // The sampled batch of the PREVIOUS round has released its ring slots: recode and park what was requested
+        // during that round (wavefronts 1-3; wavefront 0 is on its way to the totals), then request the
+        // slices / sampling inputs the ring can take once the current batch has been walked to its end.
+        // The loader wavefronts idle through the exchange and the sampling step, which hides the recoding,
+        // the marker-id round trip and most of the HBM latency.
+        prefetch_commit();
+        PROF(3);   // recode + ring write of the previous round's prefetch
         prefetch_issue(pos + cur.nb + RPOS, cur.gen + 1u);
         meta_issue(pos + cur.nb + META_POS);
         PROF(2);   // prefetch issue
@@ -1077,7 +1131,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
             Totals tot0{0.0, 0.0, 0.0, 0.0}, tot1{0.0, 0.0, 0.0, 0.0};
-            const bool okw = poll_totals(cur.nb, fast, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word);
+            const bool okw = poll_totals(cur.nb, fast, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word, spin_limit);
             if (lane == 0) *reinterpret_cast<volatile int*>(&ctl[C_TOTF]) = (int)(cur.gen + 1u);   // the loaders may start
             TRACE(3);
             PROF(4);   // wait for the totals
@@ -1104,7 +1158,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         PROF(7);   // sampling step (wavefront 0's own time)
         if (bad) ctl[C_BAD] = 1;
         lds_barrier();                                // no vmcnt drain: prefetches stay in flight
-        if (ctl[C_BAD] || ctl[C_RNGERR]) { ok = false; break; }
+        if (ctl[C_BAD] || ctl[C_RNGERR] || ctl[C_RANGE]) { ok = false; break; }
         TRACE(5);
         PROF(5);   // barrier after sampling
 
@@ -1114,23 +1168,22 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (upd) {
             n_upd++;
             const int ps = pos + ctl[C_SUPD];
-            const int ob = tid * R;                    // this thread's bytes of the slice
-            const own_t raw = *reinterpret_cast<const own_t*>(ring + (size_t)((unsigned)ps % (unsigned)RPOS) * SB +
-                                                              16 * ((ob >> 4) ^ (ps & (CPP - 1))) + (ob & 15));
-            const uint32_t wd = (uint32_t)(own_t)((raw & own_keep) | own_force);
+            // this thread's ND dwords of the slice: field o_fld of each byte is one of its individuals (ring codes c')
+            const char* own = ring + (size_t)((unsigned)ps % (unsigned)RPOS) * SB + 16 * (o_chunk ^ (ps & (CPP - 1))) + o_jb;
 #pragma unroll
-            for (int i = 0; i < NI; i++) eps[i] += s_val[(wd >> (2 * i)) & 3u];
+            for (int d = 0; d < ND; d++) {
+                const uint32_t cd = (*reinterpret_cast<const uint32_t*>(own + 4 * d) | na_or[d]) >> (2 * o_fld);
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) eps[4 * d + bb] += s_val[(cd >> (8 * bb)) & 3u];
+            }
             refresh_planes();
         }
         pos += n_done;
         n_batch++;
         TRACE(6);
         PROF(6);   // residual update + plane refresh
-        // the sampled batch has released its ring slots: park what was requested before the sampling step
         const bool will_restart = upd || n_done < cur.nb || !have_next;
-        prefetch_commit();
         meta_commit();
-        PROF(3);   // ring write of the prefetch
         if (ctl[C_CURSOR] >= 624) block_advance(s_rng0, s_rng1, ctl, true);
         if (will_restart) {                           // the speculative batch (if any) is stale: restart
             if (have_next) n_disc++;
@@ -1142,18 +1195,21 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
     }
 
+    if (ok) {                                         // a range violation in the last update is seen here
+        __syncthreads();
+        if (ctl[C_RANGE]) ok = false;
+    }
     if (!ok) {
         if (tid == 0) {
             st_u32(abort_word, 1u);
-            atomicMax(a.err, ctl[C_RNGERR] ? 2 : 1);
+            atomicMax(a.err, ctl[C_RANGE] ? 4 : (ctl[C_RNGERR] ? 2 : 1));
         }
         return;
     }
-    __syncthreads();
     if (ctl[C_CURSOR] >= 624) block_advance(s_rng0, s_rng1, ctl, true);
     if (valid) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) a.eps[4 * b0 + i] = eps[i];
+        for (int q = 0; q < NI; q++) a.eps[4 * (o_byte + (size_t)q) + (size_t)o_fld] = eps[q];
     }
     if (wg == 0) {
         for (int i = tid; i < 624; i += SW_TPB) a.rng_state[i] = s_rng0[i];
@@ -1182,23 +1238,50 @@ int sweep_pick_R(size_t stride, int max_wg, int* W_out) {
     return -1;
 }
 
-template <int R, bool FAST> static hipError_t launch_RF(const SweepArgs& a, hipStream_t st) {
+template <int R, bool FAST> static hipError_t launch_RF(const SweepArgs& a, hipStream_t st, int grid) {
     const int lds = lds_total<R>();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_sweep<R, FAST>), dim3(a.W), dim3(SW_TPB), lds, st, a);
+    hipLaunchKernelGGL((k_sweep<R, FAST>), dim3(grid), dim3(SW_TPB), lds, st, a);
     return hipGetLastError();
 }
-template <int R> static hipError_t launch_R(const SweepArgs& a, hipStream_t st) {
-    return a.all_nomiss ? launch_RF<R, true>(a, st) : launch_RF<R, false>(a, st);
+template <int R> static hipError_t launch_R(const SweepArgs& a, hipStream_t st, int grid) {
+    return a.all_nomiss ? launch_RF<R, true>(a, st, grid) : launch_RF<R, false>(a, st, grid);
 }
 
-hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st) {
-    if (a.W > SW_TPB) return hipErrorInvalidValue;
+// `grid` is a.W except in the fault-injection test (one workgroup short: the grid-wide wait must time out).
+hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) {
+    if (a.W > SW_TPB || grid < 1 || grid > a.W) return hipErrorInvalidValue;
     switch (R) {
-        case 1: return launch_R<1>(a, st);
-        case 2: return launch_R<2>(a, st);
-        case 4: return launch_R<4>(a, st);
+        case 1: return launch_R<1>(a, st, grid);
+        case 2: return launch_R<2>(a, st, grid);
+        case 4: return launch_R<4>(a, st, grid);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// Resident workgroups per compute unit for the sweep kernel at this R (the smaller of the two exchange
+// layouts' answers): the kernel's workgroups wait for each other, so a launch is only legal when the
+// whole grid is resident.  The LDS request (> 80 KiB) makes this 1.
+template <int R> static hipError_t occupancy_R(int* out) {
+    const int lds = lds_total<R>();
+    int n0 = 0, n1 = 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_sweep<R, true>, SW_TPB, (size_t)lds);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_sweep<R, false>, SW_TPB, (size_t)lds);
+    if (e != hipSuccess) return e;
+    *out = n0 < n1 ? n0 : n1;
+    return hipSuccess;
+}
+hipError_t sweep_occupancy(int R, int* blocks_per_cu) {
+    switch (R) {
+        case 1: return occupancy_R<1>(blocks_per_cu);
+        case 2: return occupancy_R<2>(blocks_per_cu);
+        case 4: return occupancy_R<4>(blocks_per_cu);
         default: return hipErrorInvalidValue;
     }
 }

@@ -10,7 +10,7 @@
 //   src/bayes.cpp:867-900        .bed block read (here: chunked pread -> gmrm_upload_bed)
 //   src/phenotype.cpp:587-621    --phen-files tokenising
 //   src/bayes.cpp:659-669, src/xfiles.hpp:14-38, src/xfiles.cpp:6-47   .csv/.bet/.cpn records
-// Not provided: --predict (post-processing, outside the hot path; DESIGN.md "Out of scope").
+//   src/bayes.cpp:16-284         --predict (run_predict below: posterior means from .bet, g = Z beta, .mlma records)
 #include "../../include/gmrm_hip.h"
 
 #include <fcntl.h>
@@ -436,6 +436,12 @@ int main(int argc, char** argv) {
         need(gmrm_group_create(&grp, nsh, ctxs.data(), smps.data(), G, K, opt.no_rccl ? 0 : 1), "gmrm_group_create");
         printf("INFO   : %d marker shards, residual exchange once per sweep through %s.\n", nsh,
                gmrm_group_uses_rccl(grp) ? "RCCL (ncclAllReduce)" : "host memory");
+        // the sweep-synchronous schedule is an approximation of the sequential scan, not the
+        // reference's per-step exchange (bayes.cpp:495-553) -- say so instead of running it silently.
+        printf("WARNING: %d shards sweep their blocks against per-shard residual replicas that are reconciled ONCE per sweep.\n"
+               "       : This is not the Markov chain of `mpiexec -n %d gmrm` (exchange after every marker step) nor the 1-shard chain;\n"
+               "       : markers in LD that sit in different shards see each other's updates one sweep late.  Use 1 shard for the reference chain.\n",
+               nsh, nsh);
     }
 
     // phenotype.cpp:129-143: <out_dir>/<phen stem>.{bet,cpn,csv}

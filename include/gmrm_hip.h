@@ -57,6 +57,18 @@ int  gmrm_device_count(void);            /* 0 when no HIP device is visible */
 int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int T);
 int gmrm_ctx_destroy(gmrm_ctx* ctx);
 int gmrm_ctx_sync(gmrm_ctx* ctx);                      /* wait for every stream of ctx */
+/* Launch geometry of the persistent marker-loop kernel chosen for this context (no reference
+ * counterpart: upstream's parallelism is `#pragma omp parallel for` inside each call).  The kernel's
+ * workgroups wait for each other, so all of them must be resident at once: gmrm_ctx_create checks
+ * W * conc against the occupancy query and refuses geometries that cannot be co-resident. */
+typedef struct gmrm_geometry {
+    int R;                 /* genotype bytes of a column per thread (1, 2 or 4)                  */
+    int W;                 /* workgroups of one chain's launch (one per CU)                      */
+    int conc;              /* chains of this context that sweep side by side                     */
+    int num_cu;            /* compute units of the device                                        */
+    int max_resident_wg;   /* occupancy query x num_cu for the sweep kernel                      */
+} gmrm_geometry;
+int gmrm_ctx_geometry(const gmrm_ctx* ctx, gmrm_geometry* out);
 
 /* Genotypes: Bayes::load_genotype (src/bayes.cpp:867-900).  `cols` is marker-major,
  * ceil(N/4) bytes per marker, PLINK 2-bit codes LSB first (no 3-byte magic). */

@@ -1,0 +1,202 @@
+// Micro-benchmark of an MFMA phase A: the batch's dot products as an int8 contraction
+//   out[marker][plane] = sum_i a(code[marker][i]) * digit[i][plane]
+// on v_mfma_i32_16x16x64_i8 (M = 16 markers, N = 16 columns of which 8 are digit planes, K = 64
+// individuals), against the v_dot4c loop of phase_a2.hip (125 cycles per marker at R = 2).
+//
+// Operand A (genotypes -> int8) is the cost; two ways are measured:
+//   V0  "fields": the ring holds RECODED genotypes c' (00 -> 10, 01 -> 11, 10 -> 01, 11 -> 00, i.e. the
+//       2-bit field IS the a-value 2/1/0; 3 = missing, which only occurs where the residual is 0).  A lane
+//       reads one 16-byte chunk (64 individuals) and feeds 4 MFMAs, MFMA i taking field i of each of
+//       the 4 dwords: regs = dword & (0x03030303 << 2i) -- ONE v_and per register, the factor 4^i of
+//       fields 1 and 2 is divided out of the accumulator afterwards (separate accumulators per field;
+//       field 3 needs a shift first).  20 VALU operations per 4 MFMAs.  Operand B is stored in the
+//       matching individual order (position 16 i + 4 j + b of a chunk <- individual 16 j + 4 b + i).
+//   V1  "lut": raw .bed codes, one SDWA shift + one ds_read_b32 of a 256 x 4-byte table per genotype
+//       byte (natural individual order).
+// Both are exact integer arithmetic and are checked against a CPU loop.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/phase_a_mfma.hip -o tools/micro/bin/phase_a_mfma
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+
+constexpr int SB = 512;            // slice bytes per workgroup (R = 2): 2048 individuals
+constexpr int CPP = SB / 16;       // 16-byte chunks per slice
+constexpr int RING = 240;          // ring positions
+constexpr int PSTRIDE = 4 * SB + 16;   // bytes per digit plane in LDS (+16: 16 planes hit different banks)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t recode(uint32_t w) {      // c -> c' per 2-bit field
+    return (~w & 0xAAAAAAAAu) | ((w ^ (w >> 1)) & 0x55555555u);
+}
+
+template <int V>
+__global__ __launch_bounds__(256, 1) void k(const uint8_t* ringsrc, const int* q1src, const int* q2src,
+                                            long long* out, long long* cyc, int iters, int nb) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint8_t* ring = smem;                                   // RING * SB, 16-B chunks swizzled by position
+    uint8_t* planes = smem + RING * SB;                     // 8 planes x PSTRIDE (columns 8..15 of B are zero registers)
+    uint32_t* lut = reinterpret_cast<uint32_t*>(planes + 8 * PSTRIDE);       // 256
+    unsigned long long* sall = reinterpret_cast<unsigned long long*>(lut + 256);   // 128 * 2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < RING * SB / 16; i += 256) {
+        const int pos = i / CPP, c = i % CPP;
+        uint4 v = reinterpret_cast<const uint4*>(ringsrc)[i];
+        if (V == 0) { v.x = recode(v.x); v.y = recode(v.y); v.z = recode(v.z); v.w = recode(v.w); }
+        reinterpret_cast<uint4*>(ring)[pos * CPP + (c ^ (pos & (CPP - 1)))] = v;
+    }
+    // digit planes: plane p (0..3 of q1, 4..7 of q2), one byte per individual
+    for (int ind = tid; ind < 4 * SB; ind += 256) {
+        int a = q1src[ind], b = q2src[ind];
+        const int chunk = ind / 64, r = ind % 64;           // r = 16 j + 4 b + i  (dword j, byte b, field i)
+        const int at = V == 0 ? chunk * 64 + 16 * (r & 3) + 4 * (r >> 4) + ((r >> 2) & 3) : ind;
+        for (int pl = 0; pl < 4; pl++) {                    // signed base-256 digits
+            const int da = (int)(int8_t)(a & 0xff), db = (int)(int8_t)(b & 0xff);
+            planes[pl * PSTRIDE + at] = (uint8_t)da; planes[(4 + pl) * PSTRIDE + at] = (uint8_t)db;
+            a = (a - da) >> 8; b = (b - db) >> 8;
+        }
+    }
+    {
+        uint32_t w = 0;
+        for (int j = 0; j < 4; j++) { const int c = (tid >> (2 * j)) & 3; w |= (uint32_t)(c == 0 ? 2 : (c == 2 ? 1 : 0)) << (8 * j); }
+        lut[tid] = w;
+    }
+    sall[tid] = 0;
+    __syncthreads();
+
+    // work split: nt tiles of 16 markers; 4 waves = tsplit x ksplit
+    const int nt = (nb + 15) / 16;
+    const int tsplit = nt >= 4 ? 4 : (nt >= 2 ? 2 : 1), ksplit = 4 / tsplit;
+    const int wt = wave % tsplit, wk = wave / tsplit;
+    const int nss = (SB / 64) / ksplit;                     // super-steps (64 bytes = 256 individuals) per wave
+    const int ss0 = wk * nss;
+    const int mrow = lane & 15, kg = lane >> 4;
+    const uint32_t M0 = 0x03030303u;
+    long long t0 = clock64(); const long long w0 = wall_clock64();
+    long long sink = 0;
+    for (int it = 0; it < iters; it++) {
+        const int pbase = (it * 7) % RING;
+        for (int t = wt; t < nt; t += tsplit) {
+            const int mk = 16 * t + mrow;
+            const int pos = (pbase + (mk < nb ? mk : nb - 1)) % RING;
+            const uint8_t* slice = ring + pos * SB;
+            const int swz = pos & (CPP - 1);
+            v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+            // software pipeline: the reads of super-step s + 1 are in flight during the MFMAs of s
+            auto load_w = [&](int s) {
+                const int chunk = 4 * (ss0 + (s < nss ? s : nss - 1)) + kg;
+                return *reinterpret_cast<const uint4*>(slice + 16 * (chunk ^ swz));
+            };
+            struct BB { v4i b0, b1, b2, b3; };
+            auto load_b = [&](int s) {
+                BB r{{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                const int chunk = 4 * (ss0 + (s < nss ? s : nss - 1)) + kg;
+                const uint8_t* pb = planes + (mrow & 7) * PSTRIDE + chunk * 64;     // columns 8..15 duplicate 0..7 (ignored)
+                r.b0 = *reinterpret_cast<const v4i*>(pb);
+                r.b1 = *reinterpret_cast<const v4i*>(pb + 16);
+                r.b2 = *reinterpret_cast<const v4i*>(pb + 32);
+                r.b3 = *reinterpret_cast<const v4i*>(pb + 48);
+                return r;
+            };
+            uint4 w = load_w(0);
+            BB bb = load_b(0);
+#pragma unroll 2
+            for (int s = 0; s < nss; s++) {
+                const uint4 wn = load_w(s + 1);
+                const BB bn = load_b(s + 1);
+                const v4i b0 = bb.b0, b1 = bb.b1, b2 = bb.b2, b3 = bb.b3;
+                if (V == 0) {
+                    const v4i a0 = {(int)(w.x & M0), (int)(w.y & M0), (int)(w.z & M0), (int)(w.w & M0)};
+                    const v4i a1 = {(int)(w.x & (M0 << 2)), (int)(w.y & (M0 << 2)), (int)(w.z & (M0 << 2)), (int)(w.w & (M0 << 2))};
+                    const v4i a2 = {(int)(w.x & (M0 << 4)), (int)(w.y & (M0 << 4)), (int)(w.z & (M0 << 4)), (int)(w.w & (M0 << 4))};
+                    const v4i a3 = {(int)((w.x >> 6) & M0), (int)((w.y >> 6) & M0), (int)((w.z >> 6) & M0), (int)((w.w >> 6) & M0)};
+                    acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc2, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, b3, acc0, 0, 0, 0);
+                } else {
+#define LUT4(W) v4i{(int)lut[(W) & 0xffu], (int)lut[((W) >> 8) & 0xffu], (int)lut[((W) >> 16) & 0xffu], (int)lut[(W) >> 24]}
+                    const v4i a0 = LUT4(w.x), a1 = LUT4(w.y), a2 = LUT4(w.z), a3 = LUT4(w.w);
+#undef LUT4
+                    acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, b3, acc0, 0, 0, 0);
+                }
+                w = wn; bb = bn;
+            }
+            // C: column n = lane & 15 (plane), rows 4 kg + r (marker of the tile)
+            const int n = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int v = V == 0 ? acc0[r] + (acc1[r] >> 2) + (acc2[r] >> 4) : acc0[r];
+                long long x = (long long)v << (8 * (n & 3));
+                // sum over the quad (planes 4q .. 4q+3): DPP quad_perm adds on both halves
+                int lo = (int)x, hi = (int)(x >> 32);
+                long long y = x + (((long long)__builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false) << 32) | (unsigned)__builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false));
+                lo = (int)y; hi = (int)(y >> 32);
+                y = y + (((long long)__builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xf, 0xf, false) << 32) | (unsigned)__builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xf, 0xf, false));
+                const int m = 16 * t + 4 * kg + r;
+                if ((n & 3) == 0 && n < 8 && m < nb) atomicAdd(&sall[m * 2 + (n >> 2)], (unsigned long long)y);
+            }
+        }
+        __syncthreads();
+        if (it == 0 && tid < nb * 2) out[(size_t)blockIdx.x * 256 + tid] = (long long)sall[tid];
+        if (tid < nb * 2) { sink += (long long)sall[tid]; sall[tid] = 0; }
+        __syncthreads();
+    }
+    const long long t1 = clock64();
+    if (tid == 0) { cyc[blockIdx.x] = t1 - t0; cyc[gridDim.x + blockIdx.x] = wall_clock64() - w0; if (sink == 0x1234567) out[0] = sink; }
+}
+
+template <int V> static void run(const char* name, int nbv) {
+    const int blocks = 245, iters = 200;
+    std::vector<uint8_t> ring((size_t)RING * SB);
+    std::vector<int> q1(SB * 4), q2(SB * 4);
+    srand(7);
+    for (auto& b : ring) b = (uint8_t)(rand() & 0xff);
+    for (auto& x : q1) x = (int)((((long long)rand() << 16) ^ rand()) % (1ll << 30)) * ((rand() & 1) ? 1 : -1);
+    for (auto& x : q2) x = (int)((((long long)rand() << 16) ^ rand()) % (1ll << 30)) * ((rand() & 1) ? 1 : -1);
+    // V0 treats code 01 (missing) as a = 3: only legal where the residual is 0
+    for (int m = 0; m < RING; m++)
+        for (int g = 0; g < SB; g++)
+            for (int j = 0; j < 4; j++)
+                if (((ring[(size_t)m * SB + g] >> (2 * j)) & 3) == 1) ring[(size_t)m * SB + g] ^= (uint8_t)(2u << (2 * j));   // 01 -> 11
+    uint8_t* dr; int *d1, *d2; long long *dout, *dc;
+    hipMalloc(&dr, ring.size()); hipMalloc(&d1, q1.size() * 4); hipMalloc(&d2, q2.size() * 4);
+    hipMalloc(&dout, (size_t)blocks * 256 * 8); hipMalloc(&dc, blocks * 16);
+    hipMemcpy(dr, ring.data(), ring.size(), hipMemcpyHostToDevice);
+    hipMemcpy(d1, q1.data(), q1.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d2, q2.data(), q2.size() * 4, hipMemcpyHostToDevice);
+    const size_t sm = (size_t)RING * SB + 8 * PSTRIDE + 1024 + 256 * 8;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k<V>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), sm, 0, dr, d1, d2, dout, dc, iters, nbv);
+    hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(256), sm, 0, dr, d1, d2, dout, dc, iters, nbv);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed\n", name); return; }
+    std::vector<long long> out((size_t)blocks * 256), cyc(blocks * 2);
+    hipMemcpy(out.data(), dout, out.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(cyc.data(), dc, cyc.size() * 8, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int m = 0; m < nbv; m++) {                         // iteration 0 (pbase = 0): marker m = ring position m
+        long long s1 = 0, s2 = 0;
+        for (int g = 0; g < SB; g++) {
+            const uint8_t b = ring[(size_t)m * SB + g];
+            for (int j = 0; j < 4; j++) {
+                const int c = (b >> (2 * j)) & 3; const int a = c == 0 ? 2 : (c == 2 ? 1 : 0);
+                s1 += (long long)a * q1[g * 4 + j]; s2 += (long long)a * q2[g * 4 + j];
+            }
+        }
+        if (out[m * 2] != s1 || out[m * 2 + 1] != s2) bad++;
+    }
+    double avg = 0, wl = 0; for (int i = 0; i < blocks; i++) { avg += (double)cyc[i]; wl += (double)cyc[blocks + i]; } avg /= blocks; wl /= blocks;
+    printf("%-28s markers %3d: %8.0f clk/batch  %6.1f clk/marker  %6.2f us/batch (%s)\n", name, nbv, avg / iters, avg / iters / nbv, wl / iters * 0.01, bad ? "MISMATCH" : "exact");
+    hipFree(dr); hipFree(d1); hipFree(d2); hipFree(dout); hipFree(dc);
+}
+
+int main() {
+    for (int nb : {128, 120, 64, 32, 16}) run<0>("mfma i8, recoded fields", nb);
+    for (int nb : {128, 64, 16}) run<1>("mfma i8, byte table in LDS", nb);
+    return 0;
+}
