@@ -66,6 +66,8 @@ class Hyper:
     n_updates: int
     n_batches: int
     sweep_device_ms: float
+    n_planned_stops: int = 0
+    n_stale_dots: int = 0
 
 
 class Context:
@@ -328,7 +330,8 @@ class Sampler:
         h = _lib.HyperC()
         check(self.lib.gmrm_sampler_get(self.h, int(t), C.byref(h)))
         return Hyper(h.sigmae, h.mu, h.m0_sum, np.array(h.sigmag[:self.G]),
-                     np.array(h.pi_est[:self.G * self.K]), h.n_updates, h.n_batches, h.sweep_device_ms)
+                     np.array(h.pi_est[:self.G * self.K]), h.n_updates, h.n_batches, h.sweep_device_ms,
+                     h.n_planned_stops, h.n_stale_dots)
 
     def csv_line(self, t, it) -> bytes:
         buf = C.create_string_buffer(50000)      # LENBUF, src/const.hpp:3

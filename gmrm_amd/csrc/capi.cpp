@@ -145,7 +145,7 @@ static int ctx_create_body(gmrm_ctx* c, int device, int N, int M, int Mt, int S,
         HIPCHK(dalloc(&tr.rng_state, (size_t)624));
         HIPCHK(dalloc(&tr.rng_index, (size_t)4));
         HIPCHK(dalloc(&tr.cass, (size_t)GMAX * KMAX));
-        HIPCHK(dalloc(&tr.stats, (size_t)24));
+        HIPCHK(dalloc(&tr.stats, (size_t)40));
         HIPCHK(dalloc(&tr.err, (size_t)4));
         HIPCHK(dalloc(&tr.P, (size_t)4 * SW_VMAX * c->Wpad));       // 2 generations x two 8-byte granules per value
         HIPCHK(dalloc(&tr.Tt, (size_t)4 * SW_VMAX));
@@ -555,7 +555,8 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     HIPCHK(hipMemsetAsync(tr.P, 0, (size_t)4 * SW_VMAX * c->Wpad * sizeof(double), tr.stream));
     HIPCHK(hipMemsetAsync(tr.Tt, 0, (size_t)4 * SW_VMAX * sizeof(double), tr.stream));
     HIPCHK(hipMemsetAsync(tr.err, 0, 4 * sizeof(int), tr.stream));
-    HIPCHK(hipMemsetAsync(tr.stats, 0, 24 * sizeof(long long), tr.stream));
+    HIPCHK(hipMemsetAsync(tr.cass, 0, (size_t)GMAX * KMAX * sizeof(int), tr.stream));   // every workgroup adds its share
+    HIPCHK(hipMemsetAsync(tr.stats, 0, 40 * sizeof(long long), tr.stream));
 
     SweepArgs a{};
     a.N = c->N; a.M = c->M; a.W = c->W; a.Wpad = c->Wpad; a.G = G; a.K = K;
@@ -619,7 +620,7 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
     if (!tr.in_flight) return fail(GMRM_ESTATE, "no sweep in flight for this phenotype");
     tr.in_flight = false;
     if (tr.empty) {
-        if (out) { out->n_updates = 0; out->n_batches = 0; out->device_ms = 0.0;
+        if (out) { out->n_updates = 0; out->n_batches = 0; out->device_ms = 0.0; out->n_planned_stops = 0; out->n_stale_dots = 0;
                    if (out->cass) std::memset(out->cass, 0, sizeof(int) * (size_t)tr.G * tr.K); }
         return GMRM_OK;
     }
@@ -645,9 +646,9 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
     }
     tr.cur ^= 1;
     if (out) {
-        long long st[24];
+        long long st[40];
         HIPCHK(hipMemcpy(st, tr.stats, sizeof(st), hipMemcpyDeviceToHost));
-        out->n_updates = st[0]; out->n_batches = st[1];
+        out->n_updates = st[0]; out->n_batches = st[1]; out->n_planned_stops = st[29]; out->n_stale_dots = st[30];
         if (const char* path = std::getenv("GMRM_SWEEP_TRACE")) {
             if (tr.trace) {
                 std::vector<unsigned long long> h((size_t)256 * 64 * 8);
@@ -666,6 +667,9 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
             std::fprintf(stderr, "[sweep prof sampler wg W/2] inputs %.2fus decide0 %.2fus search %.2fus commit %.2fus\n",
                          st[20] * 0.01 / (double)st[1], st[21] * 0.01 / (double)st[1], st[22] * 0.01 / (double)st[1],
                          st[23] * 0.01 / (double)st[1]);
+            std::fprintf(stderr, "[sweep prof phase A wg W/2] loop top -> barrier %.2fus scan+inputs %.2fus tiles %.2fus barrier %.2fus publish %.2fus (max batch %lld)\n",
+                         st[24] * 0.01 / (double)st[1], st[25] * 0.01 / (double)st[1], st[26] * 0.01 / (double)st[1],
+                         st[27] * 0.01 / (double)st[1], st[28] * 0.01 / (double)st[1], st[2]);
         }
         if (out->cass) HIPCHK(hipMemcpy(out->cass, tr.cass, sizeof(int) * (size_t)tr.G * tr.K, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(out->rng_state, tr.rng_state, 624 * sizeof(uint32_t), hipMemcpyDeviceToHost));

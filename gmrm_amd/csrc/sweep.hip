@@ -73,7 +73,11 @@ template <int R> struct Geo {
     static constexpr int PPI = NL / CPP;                  // positions covered by one load instruction
     static constexpr int PFG = 4;                         // loads per wave-uniform branch
     static constexpr int PFN = ((BMAXF + PPI - 1) / PPI + PFG - 1) / PFG * PFG;   // loads per loader thread per round
-    static constexpr int PSTRIDE = 4 * SB + 16;           // bytes per digit plane (one per individual; +16: the planes start on different banks)
+    // Digit plane n (one byte per individual) starts at n * PSTRIDE + (n >> 2) * 64 bytes: in phase A a 16-lane
+    // LDS access group holds 8 planes x 2 lane groups (64 bytes apart) reading 16 bytes each, and these
+    // offsets put the 16 reads on 16 different bank quads (n * 16 + (n >> 2) * 64 + kg * 64 bytes, mod 256).
+    static constexpr int PSTRIDE = 4 * SB + 16;
+    static constexpr int PLANES = 8 * PSTRIDE + 64;       // bytes of the eight planes
     static_assert(NL % CPP == 0 && PPI >= 1, "loader mapping");
     static_assert(2 * BMAXF + 2 <= SW_VMAX && 4 * BMAXG <= SW_VMAX, "exchange rows");
 };
@@ -94,7 +98,7 @@ constexpr int META_POS = 256;                   // per-marker inputs of the samp
 constexpr int L_META = L_TAB + TAB_LDS * 8;     // int m[256], int g[256], double beta[256], mave[256], msig[256]
 constexpr int L_TOT  = L_META + META_POS * 32;  // double[SW_VMAX]: the batch totals as wavefront 0 fetched them
 constexpr int L_PLN  = L_TOT + SW_VMAX * 8;     // uint8[8][PSTRIDE]: digit planes of the residual (operand B order)
-template <int R> constexpr int l_ring() { return L_PLN + 8 * Geo<R>::PSTRIDE; }
+template <int R> constexpr int l_ring() { return L_PLN + Geo<R>::PLANES; }
 static_assert(L_PLN % 16 == 0, "LDS carve");
 // Request > 80 KiB so that exactly one workgroup fits per CU.
 constexpr int L_MIN = 84 * 1024;
@@ -103,7 +107,7 @@ template <int R> constexpr int lds_total() {
 }
 static_assert(lds_total<1>() <= 160 * 1024 && lds_total<2>() <= 160 * 1024 && lds_total<4>() <= 160 * 1024, "LDS budget");
 
-enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD, C_TOTF, C_RANGE };
+enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD, C_TOTF, C_RANGE, C_PLN };
 
 size_t sweep_lds_bytes() { return (size_t)lds_total<2>(); }   // the largest of the three carves
 
@@ -248,10 +252,14 @@ __device__ __forceinline__ double decide0(double num, const double* denom_g, con
         muk[i] = num / denom_g[i];
         logl[i] = logpi_g[i] + (mhl_g[i] + muk[i] * num * inv2sige);
     }
+    // bayes.cpp:437-445: tmp1 = sum_i exp(logl[i] - logl[0]).  Term 0 is exp(0) = 1 exactly (0.0 + 1.0 = 1.0) whenever
+    // logl[0] is finite; a non-finite logl[0] (pi_0 == 0) makes every difference non-finite: |d| > 700 is false for
+    // NaN, the sum is NaN and the comparison `prob <= acum` false -- reproduced by adding the NaN term itself.
     bool zero_acum = false;
-    double tmp1 = 0.0;
+    const double d0 = logl[0] - logl[0];
+    double tmp1 = (d0 == 0.0) ? 1.0 : d0;            // 1.0, or NaN
 #pragma unroll
-    for (int i = 0; i < K; i++) {
+    for (int i = 1; i < K; i++) {
         const double d = logl[i] - logl[0];
         if (fabs(d) > 700.0) zero_acum = true;
         tmp1 += (d == 0.0) ? 1.0 : exp_(d);          // exp_(0) is exactly 1
@@ -466,6 +474,7 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
         ctl[C_CURSOR] = cursor;
         ctl[C_NDONE] = nb;
     }
+    if (lane == 0) ctl[C_PLN] = planned ? 1 : 0;
     if (lane == 0 && !planned) {                                     // next batch size from the recent run length
         const int ema = (3 * ctl[C_EMA] + 16 * run) / 4;            // fixed point, 1/16 marker
         ctl[C_EMA] = ema;
@@ -581,27 +590,50 @@ __device__ __forceinline__ long long quad_sum64(long long x) {
     return y;
 }
 
-// One super-step's LDS operands: the lane's 16-byte chunk of its marker's slice (operand A before the
-// field masks) and the 64 bytes of its digit plane (operand B of the four MFMAs).  The reads are inline
-// asm so that they can be issued a whole super-step ahead of their use: hipcc does not count them, the
-// matching stage_wait<N> does (N = LDS reads issued after this stage's; LDS returns in order).
-struct Stage { u32x4 w; v4i b0, b1, b2, b3; };   // native vector types: "+v" operands must be registers
-__device__ __forceinline__ Stage stage_read(uint32_t waddr, uint32_t baddr) {
-    u32x4 w; v4i b0, b1, b2, b3;
-    asm volatile("ds_read_b128 %0, %5\n\t"
-                 "ds_read_b128 %1, %6\n\t"
-                 "ds_read_b128 %2, %6 offset:16\n\t"
-                 "ds_read_b128 %3, %6 offset:32\n\t"
-                 "ds_read_b128 %4, %6 offset:48"
-                 : "=&v"(w), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(waddr), "v"(baddr) : "memory");
-    return Stage{w, b0, b1, b2, b3};
+// One super-step's LDS operands: the 64 bytes of the lane's digit plane (operand B of the four MFMAs) and the
+// lane's 16-byte chunk of its marker's slice (operand A before the field masks) for the ONE or TWO tiles the
+// wavefront works on (B is shared by both).  The reads are inline asm so that they can be issued a whole
+// super-step ahead of their use: hipcc does not count them, the matching stage_wait does (N = LDS reads
+// issued after this stage's; LDS returns in order).  Native vector types: "+v" operands must be registers.
+template <int NT> struct Stage { v4i b0, b1, b2, b3; u32x4 w[NT]; };
+template <int NT> __device__ __forceinline__ Stage<NT> stage_read(uint32_t baddr, uint32_t waddr0, uint32_t waddr1) {
+    Stage<NT> st;
+    v4i b0, b1, b2, b3; u32x4 w0, w1;
+    if constexpr (NT == 2) {
+        asm volatile("ds_read_b128 %0, %6\n\t"
+                     "ds_read_b128 %1, %6 offset:16\n\t"
+                     "ds_read_b128 %2, %6 offset:32\n\t"
+                     "ds_read_b128 %3, %6 offset:48\n\t"
+                     "ds_read_b128 %4, %7\n\t"
+                     "ds_read_b128 %5, %8"
+                     : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(w0), "=&v"(w1) : "v"(baddr), "v"(waddr0), "v"(waddr1) : "memory");
+        st.w[1] = w1;
+    } else {
+        asm volatile("ds_read_b128 %0, %5\n\t"
+                     "ds_read_b128 %1, %5 offset:16\n\t"
+                     "ds_read_b128 %2, %5 offset:32\n\t"
+                     "ds_read_b128 %3, %5 offset:48\n\t"
+                     "ds_read_b128 %4, %6"
+                     : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(w0) : "v"(baddr), "v"(waddr0) : "memory");
+    }
+    st.b0 = b0; st.b1 = b1; st.b2 = b2; st.b3 = b3; st.w[0] = w0;
+    return st;
 }
-template <int N> __device__ __forceinline__ Stage stage_wait(const Stage st) {
-    static_assert(N == 0 || N == 5, "reads of one later stage, or none");
-    u32x4 w = st.w; v4i b0 = st.b0, b1 = st.b1, b2 = st.b2, b3 = st.b3;
-    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : : "memory");
-    else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(w), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : : "memory");
-    return Stage{w, b0, b1, b2, b3};
+// wait until this stage's reads have landed; `later` = true: the NT + 4 reads of the next stage stay in flight
+template <int NT, bool LATER> __device__ __forceinline__ Stage<NT> stage_wait(const Stage<NT> st) {
+    v4i b0 = st.b0, b1 = st.b1, b2 = st.b2, b3 = st.b3; u32x4 w0 = st.w[0];
+    Stage<NT> r;
+    if constexpr (NT == 2) {
+        u32x4 w1 = st.w[1];
+        if constexpr (LATER) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(w0), "+v"(w1) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(w0), "+v"(w1) : : "memory");
+        r.w[1] = w1;
+    } else {
+        if constexpr (LATER) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(w0) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(w0) : : "memory");
+    }
+    r.b0 = b0; r.b1 = b1; r.b2 = b2; r.b3 = b3; r.w[0] = w0;
+    return r;
 }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
@@ -706,7 +738,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
 #pragma unroll
         for (int n = 0; n < 8; n++) {
-            char* dst = planes + n * PST + p0w;
+            char* dst = planes + n * PST + (n >> 2) * 64 + p0w;
             if constexpr (ND == 1) *reinterpret_cast<uint32_t*>(dst) = pl[n][0];
             else if constexpr (ND == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pl[n][0], pl[n][1]);
             else *reinterpret_cast<uint4*>(dst) = make_uint4(pl[n][0], pl[n][1], pl[n][2], pl[n][3]);
@@ -896,17 +928,25 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // workgroup has sampled the generation that used it.
     struct Batch { int p0, nb, nv; unsigned gen; bool planned; };   // planned: ends at a marker known to stop the walk
     unsigned gen_next = 0;
-    long long n_upd = 0, n_batch = 0, n_disc = 0;
+    long long n_upd = 0, n_batch = 0, n_disc = 0, n_planned = 0, n_stale = 0;
     int max_nb = 0;
     bool ok = true;
 #ifdef GM_SWEEP_PROF
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pa[5] = {0, 0, 0, 0, 0};      // phase A: entry barrier, scan + inputs, tiles, exit barrier, publish
     unsigned long long tlast = __builtin_amdgcn_s_memrealtime();
+#define PA(i) do { if (tid == GM_PROF_TID) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); pa[i] += t_ - tpa; tpa = t_; } } while (0)
+#else
+#define PA(i) do { } while (0)
 #endif
 
     // phase A for positions [b.p0, b.p0 + b.nb) (slices already in the ring) + publish
     auto compute_publish = [&](Batch& b, LaneIn& li0, LaneIn& li1) {
+#ifdef GM_SWEEP_PROF
+        unsigned long long tpa = tlast;
+#endif
         lds_barrier();                                // ring / plane / meta writes are visible (no vmcnt drain)
+        PA(0);
         const int p0 = b.p0;
         // A marker whose effect is non-zero always changes it (bayes.cpp:479-483: the new draw differs), so
         // the walk is known to stop there: end the batch at the first such marker instead of computing dots
@@ -931,6 +971,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             li1.m = mr_m[sl]; li1.g = mr_g[sl]; li1.beta_old = mr_beta[sl]; li1.mave = mr_mave[sl]; li1.msig = mr_msig[sl];
         }
         max_nb = nb > max_nb ? nb : max_nb;
+        PA(1);
         // work split: nt tiles of 16 markers; the 4 wavefronts = tsplit tile groups x ksplit parts of the slice
         const int nt = (nb + 15) >> 4;
         const int tsplit = nt >= 4 ? 4 : (nt >= 2 ? 2 : 1);
@@ -938,52 +979,65 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         const int wt = wave & (tsplit - 1), wk = wave / tsplit;
         const int ss_lo = wk * (SS / ksplit);               // first super-step of this wavefront's part of the slice
         const int mrow = lane & 15, kg = lane >> 4;
-        const char* pbase = planes + (lane & 7) * PST + kg * 64;      // columns 8..15 of B repeat 0..7 (their results are dropped)
+        const char* pbase = planes + (lane & 7) * PST + ((lane & 7) >> 2) * 64 + kg * 64;   // columns 8..15 of B repeat 0..7 (their results are dropped)
         constexpr uint32_t M0 = 0x03030303u, M1 = 0x01010101u;
-        // One tile = 16 markers x NS super-steps of the slice starting at ss_lo.  NS is a compile-time count so
-        // that the body is ONE basic block: the LDS reads of later super-steps are issued ahead of the MFMAs
-        // of earlier ones (a wave-uniform test per super-step would serialise read -> wait -> MFMA).
-        auto tile_pass = [&](auto ns_tag, int t) {
+        // One pass = ONE or TWO tiles of 16 markers (t and t + tsplit: operand B is read once for both) x NS
+        // super-steps of the slice starting at ss_lo.  NS and the tile count are compile-time so that the body is
+        // ONE basic block; the LDS reads of super-step s + 1 are in flight during the arithmetic of s.
+        auto tile_pass = [&](auto ns_tag, auto nt_tag, int t) {
             constexpr int NS = decltype(ns_tag)::value;
-            const int mk = 16 * t + mrow;
-            const int pl = p0 + (mk < nb ? mk : nb - 1);              // idle rows shadow the last marker (their sums are dropped)
-            const char* slice = ring + (size_t)((unsigned)pl % (unsigned)RPOS) * SB;
-            const int swz = pl & (CPP - 1);
+            constexpr int NTL = decltype(nt_tag)::value;              // tiles in this pass
+            uint32_t sl0[NTL];
+            int swz[NTL];
+#pragma unroll
+            for (int q = 0; q < NTL; q++) {
+                const int mk = 16 * (t + q * tsplit) + mrow;
+                const int pl = p0 + (mk < nb ? mk : nb - 1);          // idle rows shadow the last marker (their sums are dropped)
+                sl0[q] = lds_addr(ring + (size_t)((unsigned)pl % (unsigned)RPOS) * SB);
+                swz[q] = pl & (CPP - 1);
+            }
             const uint32_t pb0 = lds_addr(pbase) + (uint32_t)ss_lo * 256u;
-            const uint32_t sl0 = lds_addr(slice);
-            v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-            v4i zcc0 = {0, 0, 0, 0}, zcc1 = {0, 0, 0, 0}, zcc2 = {0, 0, 0, 0};     // general layout: the missing-genotype indicator
-            Stage stg[2];
-            stg[0] = stage_read(sl0 + 16u * (uint32_t)((4 * ss_lo + kg) ^ swz), pb0);
+            v4i acc0[NTL], acc1[NTL], acc2[NTL], zcc0[NTL], zcc1[NTL], zcc2[NTL];   // zcc: general layout, the missing-genotype indicator
+#pragma unroll
+            for (int q = 0; q < NTL; q++) {
+                acc0[q] = v4i{0, 0, 0, 0}; acc1[q] = v4i{0, 0, 0, 0}; acc2[q] = v4i{0, 0, 0, 0};
+                zcc0[q] = v4i{0, 0, 0, 0}; zcc1[q] = v4i{0, 0, 0, 0}; zcc2[q] = v4i{0, 0, 0, 0};
+            }
+            auto waddr = [&](int q, int s) { return sl0[q] + 16u * (uint32_t)((4 * (ss_lo + s) + kg) ^ swz[q]); };
+            Stage<NTL> stg[2];
+            stg[0] = stage_read<NTL>(pb0, waddr(0, 0), waddr(NTL - 1, 0));
 #pragma unroll
             for (int s = 0; s < NS; s++) {
-                if (s + 1 < NS) {                     // the next super-step's reads are in flight during this one's arithmetic
-                    stg[(s + 1) & 1] = stage_read(sl0 + 16u * (uint32_t)((4 * (ss_lo + s + 1) + kg) ^ swz), pb0 + (uint32_t)(s + 1) * 256u);
-                    stg[s & 1] = stage_wait<5>(stg[s & 1]);
+                if (s + 1 < NS) {
+                    stg[(s + 1) & 1] = stage_read<NTL>(pb0 + (uint32_t)(s + 1) * 256u, waddr(0, s + 1), waddr(NTL - 1, s + 1));
+                    stg[s & 1] = stage_wait<NTL, true>(stg[s & 1]);
                 } else {
-                    stg[s & 1] = stage_wait<0>(stg[s & 1]);
+                    stg[s & 1] = stage_wait<NTL, false>(stg[s & 1]);
                 }
-                const u32x4 w = stg[s & 1].w;
                 const v4i b0 = stg[s & 1].b0, b1 = stg[s & 1].b1, b2 = stg[s & 1].b2, b3 = stg[s & 1].b3;
-                const v4i a0 = {(int)(w.x & M0), (int)(w.y & M0), (int)(w.z & M0), (int)(w.w & M0)};
-                const v4i a1 = {(int)(w.x & (M0 << 2)), (int)(w.y & (M0 << 2)), (int)(w.z & (M0 << 2)), (int)(w.w & (M0 << 2))};
-                const v4i a2 = {(int)(w.x & (M0 << 4)), (int)(w.y & (M0 << 4)), (int)(w.z & (M0 << 4)), (int)(w.w & (M0 << 4))};
-                const v4i a3 = {(int)((w.x >> 6) & M0), (int)((w.y >> 6) & M0), (int)((w.z >> 6) & M0), (int)((w.w >> 6) & M0)};
-                acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc2, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, b3, acc0, 0, 0, 0);
-                if (!FAST) {
-                    // 1 in the low bit of every field that reads 11 (missing): field & (field >> 1)
-                    const uint4 u = make_uint4(w.x & (w.x >> 1), w.y & (w.y >> 1), w.z & (w.z >> 1), w.w & (w.w >> 1));
-                    const v4i z0 = {(int)(u.x & M1), (int)(u.y & M1), (int)(u.z & M1), (int)(u.w & M1)};
-                    const v4i z1 = {(int)(u.x & (M1 << 2)), (int)(u.y & (M1 << 2)), (int)(u.z & (M1 << 2)), (int)(u.w & (M1 << 2))};
-                    const v4i z2 = {(int)(u.x & (M1 << 4)), (int)(u.y & (M1 << 4)), (int)(u.z & (M1 << 4)), (int)(u.w & (M1 << 4))};
-                    const v4i z3 = {(int)((u.x >> 6) & M1), (int)((u.y >> 6) & M1), (int)((u.z >> 6) & M1), (int)((u.w >> 6) & M1)};
-                    zcc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(z0, b0, zcc0, 0, 0, 0);
-                    zcc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(z1, b1, zcc1, 0, 0, 0);
-                    zcc2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(z2, b2, zcc2, 0, 0, 0);
-                    zcc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(z3, b3, zcc0, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < NTL; q++) {
+                    const u32x4 w = stg[s & 1].w[q];
+                    const v4i a0 = {(int)(w.x & M0), (int)(w.y & M0), (int)(w.z & M0), (int)(w.w & M0)};
+                    const v4i a1 = {(int)(w.x & (M0 << 2)), (int)(w.y & (M0 << 2)), (int)(w.z & (M0 << 2)), (int)(w.w & (M0 << 2))};
+                    const v4i a2 = {(int)(w.x & (M0 << 4)), (int)(w.y & (M0 << 4)), (int)(w.z & (M0 << 4)), (int)(w.w & (M0 << 4))};
+                    const v4i a3 = {(int)((w.x >> 6) & M0), (int)((w.y >> 6) & M0), (int)((w.z >> 6) & M0), (int)((w.w >> 6) & M0)};
+                    acc0[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc0[q], 0, 0, 0);
+                    acc1[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc1[q], 0, 0, 0);
+                    acc2[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc2[q], 0, 0, 0);
+                    acc0[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, b3, acc0[q], 0, 0, 0);
+                    if (!FAST) {
+                        // 1 in the low bit of every field that reads 11 (missing): field & (field >> 1)
+                        const u32x4 u = {w.x & (w.x >> 1), w.y & (w.y >> 1), w.z & (w.z >> 1), w.w & (w.w >> 1)};
+                        const v4i z0 = {(int)(u.x & M1), (int)(u.y & M1), (int)(u.z & M1), (int)(u.w & M1)};
+                        const v4i z1 = {(int)(u.x & (M1 << 2)), (int)(u.y & (M1 << 2)), (int)(u.z & (M1 << 2)), (int)(u.w & (M1 << 2))};
+                        const v4i z2 = {(int)(u.x & (M1 << 4)), (int)(u.y & (M1 << 4)), (int)(u.z & (M1 << 4)), (int)(u.w & (M1 << 4))};
+                        const v4i z3 = {(int)((u.x >> 6) & M1), (int)((u.y >> 6) & M1), (int)((u.z >> 6) & M1), (int)((u.w >> 6) & M1)};
+                        zcc0[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(z0, b0, zcc0[q], 0, 0, 0);
+                        zcc1[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(z1, b1, zcc1[q], 0, 0, 0);
+                        zcc2[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(z2, b2, zcc2[q], 0, 0, 0);
+                        zcc0[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(z3, b3, zcc0[q], 0, 0, 0);
+                    }
                 }
             }
             // C: column n = lane & 15 (digit plane), rows 4 kg + r (marker of the tile).  The four planes of
@@ -991,31 +1045,45 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             // (ksplit wavefronts) meet in LDS (integer: exact, any order).
             const int n = lane & 15;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int m = 16 * t + 4 * kg + r;
-                const int x = acc0[r] + (acc1[r] >> 2) + (acc2[r] >> 4);          // sum c' * digit (c' = a wherever the residual is not 0)
-                const long long sx = quad_sum64((long long)x << (8 * (n & 3)));
-                if (FAST) {
-                    if ((n & 3) == 0 && n < 8 && m < nb) atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)sx);
-                } else {
-                    // a = c' - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
-                    // slice's sum of d is added at the publish
-                    const int z = zcc0[r] + (zcc1[r] >> 2) + (zcc2[r] >> 4);
-                    const long long sz = quad_sum64((long long)z << (8 * (n & 3)));
-                    if ((n & 3) == 0 && n < 8 && m < nb) {
-                        atomicAdd(&s_sum[4 * m + (n >> 2)], (unsigned long long)(sx - 3 * sz));
-                        atomicAdd(&s_sum[4 * m + 2 + (n >> 2)], (unsigned long long)(-sz));
+            for (int q = 0; q < NTL; q++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int m = 16 * (t + q * tsplit) + 4 * kg + r;
+                    const int x = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);   // sum c' * digit (c' = a wherever the residual is not 0)
+                    const long long sx = quad_sum64((long long)x << (8 * (n & 3)));
+                    if (FAST) {
+                        if ((n & 3) == 0 && n < 8 && m < nb) atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)sx);
+                    } else {
+                        // a = c' - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
+                        // slice's sum of d is added at the publish
+                        const int z = zcc0[q][r] + (zcc1[q][r] >> 2) + (zcc2[q][r] >> 4);
+                        const long long sz = quad_sum64((long long)z << (8 * (n & 3)));
+                        if ((n & 3) == 0 && n < 8 && m < nb) {
+                            atomicAdd(&s_sum[4 * m + (n >> 2)], (unsigned long long)(sx - 3 * sz));
+                            atomicAdd(&s_sum[4 * m + 2 + (n >> 2)], (unsigned long long)(-sz));
+                        }
                     }
                 }
             }
         };
+        using IC1 = std::integral_constant<int, 1>;
+        using IC2 = std::integral_constant<int, 2>;
+        if (ksplit == 1) {                            // four or more tiles: every wavefront walks whole slices, two tiles at a time
 #pragma unroll 1
-        for (int t = wt; t < nt; t += tsplit) {
-            if (ksplit == 1) tile_pass(std::integral_constant<int, SS>{}, t);
-            else if (ksplit == 2) tile_pass(std::integral_constant<int, SS / 2>{}, t);
-            else tile_pass(std::integral_constant<int, SS / 4>{}, t);
+            for (int t = wt; t < nt; t += 8) {
+                if (t + 4 < nt) tile_pass(std::integral_constant<int, SS>{}, IC2{}, t);    // tiles t and t + 4 share operand B
+                else tile_pass(std::integral_constant<int, SS>{}, IC1{}, t);
+            }
+        } else {                                      // fewer tiles than wavefronts: the slice is split ksplit ways
+#pragma unroll 1
+            for (int t = wt; t < nt; t += tsplit) {
+                if (ksplit == 2) tile_pass(std::integral_constant<int, SS / 2>{}, IC1{}, t);
+                else tile_pass(std::integral_constant<int, SS / 4>{}, IC1{}, t);
+            }
         }
+        PA(2);
         lds_barrier();                                // the LDS sums are complete (prefetches stay in flight)
+        PA(3);
         const int nv = fast ? 2 * nb + 2 : 4 * nb;
         if (tid < nv) {
             double tot;
@@ -1036,6 +1104,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)tid * a.Wpad + wg), b.gen + 1u, tot);
         }
         b.nv = nv;
+        PA(4);
     };
 
     // reduce role: workgroup v sums row v of generation b.gen over all workgroups
@@ -1103,7 +1172,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (do_compute) {
             ensure(tb.p0 + tb.nb);
             ensure_meta(tb.p0 + tb.nb);
-            if (restart) compute_publish(tb, li_cur0, li_cur1); else compute_publish(tb, li_nxt0, li_nxt1);
+            // ONE inlined copy of phase A (instruction cache): the lane inputs land in temporaries first
+            LaneIn lt0{0, 0, 0.0, 0.0, 1.0}, lt1{0, 0, 0.0, 0.0, 1.0};
+            compute_publish(tb, lt0, lt1);
+            if (restart) { li_cur0 = lt0; li_cur1 = lt1; } else { li_nxt0 = lt0; li_nxt1 = lt1; }
         }
         if (restart) TRACE(1);
         PROF(1);   // dots + publish (restart: on the critical path; speculative: overlaps the exchange)
@@ -1122,9 +1194,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // the marker-id round trip and most of the HBM latency.
         prefetch_commit();
         PROF(3);   // recode + ring write of the previous round's prefetch
-        prefetch_issue(pos + cur.nb + RPOS, cur.gen + 1u);
-        meta_issue(pos + cur.nb + META_POS);
-        PROF(2);   // prefetch issue
 
         // ---- sampling step of the current batch (wavefront 0, every workgroup, identical inputs)
         if (wave == 0) {
@@ -1156,6 +1225,12 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             }
         }
         PROF(7);   // sampling step (wavefront 0's own time)
+        // request the slices / sampling inputs the ring can take once the current batch has been walked to its
+        // end.  Wavefronts 1-3 get here at once (they skip the block above) and issue while wavefront 0 samples;
+        // the column loads wait for the totals (gate inside).
+        prefetch_issue(pos + cur.nb + RPOS, cur.gen + 1u);
+        meta_issue(pos + cur.nb + META_POS);
+        PROF(2);   // prefetch issue
         if (bad) ctl[C_BAD] = 1;
         lds_barrier();                                // no vmcnt drain: prefetches stay in flight
         if (ctl[C_BAD] || ctl[C_RNGERR] || ctl[C_RANGE]) { ok = false; break; }
@@ -1165,6 +1240,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // ---- phase C: residual update of the stopping marker (its slice is in the ring) ----
         const int n_done = ctl[C_NDONE];
         const bool upd = ctl[C_UPD] != 0;
+        n_planned += ctl[C_PLN];
+        n_stale += cur.nb - n_done;                   // dots computed behind the stop: thrown away
         if (upd) {
             n_upd++;
             const int ps = pos + ctl[C_SUPD];
@@ -1211,18 +1288,21 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #pragma unroll
         for (int q = 0; q < NI; q++) a.eps[4 * (o_byte + (size_t)q) + (size_t)o_fld] = eps[q];
     }
+    for (int i = tid; i < G * K; i += SW_TPB)             // component counts: each workgroup counted the positions it wrote
+        if (s_cass[i] != 0) atomicAdd(&a.cass[i], s_cass[i]);
     if (wg == 0) {
         for (int i = tid; i < 624; i += SW_TPB) a.rng_state[i] = s_rng0[i];
-        for (int i = tid; i < G * K; i += SW_TPB) a.cass[i] = s_cass[i];
         if (tid == 0) {
             *a.rng_index = ctl[C_CURSOR];
             a.stats[0] = n_upd; a.stats[1] = n_batch; a.stats[2] = max_nb; a.stats[3] = n_disc;
+            a.stats[29] = n_planned; a.stats[30] = n_stale;
         }
     }
 #ifdef GM_SWEEP_PROF
     if (tid == GM_PROF_TID && (wg == 0 || wg == W / 2)) {
         for (int i = 0; i < 8; i++) a.stats[(wg == 0 ? 4 : 12) + i] = (long long)prof[i];
         if (wg != 0) for (int i = 0; i < 4; i++) a.stats[20 + i] = (long long)reinterpret_cast<unsigned long long*>(smem + L_M + 64)[i];
+        if (wg != 0) for (int i = 0; i < 5; i++) a.stats[24 + i] = (long long)pa[i];
     }
 #endif
 }
