@@ -242,28 +242,50 @@ __device__ void block_advance(uint32_t* s0, uint32_t* s1, int* ctl, bool copy) {
 
 // bayes.cpp:403-445 for one marker, given num (the dot product + beta*(nonas-1)): muk, logl and
 // the probability of component 0 (the first value of "acum").  Evaluated by every lane.
+// The per-group tables of the Gibbs step as one lane needs them (group g of its marker): sigmaG, and for
+// every component denom, log(pi), -0.5 log(...) (capi.cpp, gmrm_sweep_launch), read in one burst at the start of
+// the step through a pointer of KNOWN address space (a generic pointer compiles to flat loads, each followed
+// by a wait for both memory counters in the middle of the arithmetic).
+template <int K> struct LaneTab { double sg; double denom[K], logpi[K], mhl[K]; };
+typedef const __attribute__((address_space(3))) double* TabLds;      // the tables fit the LDS carve (the usual case)
+typedef const __attribute__((address_space(1))) double* TabGlobal;   // G * (1 + 3K) > TAB_LDS doubles: read from global memory
+template <int K, class TP> __device__ __forceinline__ LaneTab<K> load_tab(TP tab, int G, int g) {
+    LaneTab<K> t;
+    t.sg = tab[g];
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        t.denom[i] = tab[G + g * K + i];
+        t.logpi[i] = tab[G + G * K + g * K + i];
+        t.mhl[i] = tab[G + 2 * G * K + g * K + i];
+    }
+    return t;
+}
 template <int K>
-__device__ __forceinline__ double decide0(double num, const double* denom_g, const double* logpi_g,
-                                          const double* mhl_g, double inv2sige, double (&muk)[K], double (&logl)[K]) {
+__device__ __forceinline__ double decide0(double num, const LaneTab<K>& tb, double inv2sige, double (&muk)[K], double (&logl)[K]) {
     muk[0] = 0.0;
-    logl[0] = logpi_g[0];
+    logl[0] = tb.logpi[0];
 #pragma unroll
     for (int i = 1; i < K; i++) {
-        muk[i] = num / denom_g[i];
-        logl[i] = logpi_g[i] + (mhl_g[i] + muk[i] * num * inv2sige);
+        muk[i] = num / tb.denom[i];
+        logl[i] = tb.logpi[i] + (tb.mhl[i] + muk[i] * num * inv2sige);
     }
     // bayes.cpp:437-445: tmp1 = sum_i exp(logl[i] - logl[0]).  Term 0 is exp(0) = 1 exactly (0.0 + 1.0 = 1.0) whenever
     // logl[0] is finite; a non-finite logl[0] (pi_0 == 0) makes every difference non-finite: |d| > 700 is false for
     // NaN, the sum is NaN and the comparison `prob <= acum` false -- reproduced by adding the NaN term itself.
+    // No branch around exp_ (exp_(0) is exactly 1, exp_(NaN) is NaN): the K - 1 chains stay in one basic block
+    // and the scheduler interleaves them; each alone is a serial chain of ~30 dependent f64 operations.
     bool zero_acum = false;
     const double d0 = logl[0] - logl[0];
     double tmp1 = (d0 == 0.0) ? 1.0 : d0;            // 1.0, or NaN
+    double e[K];
 #pragma unroll
     for (int i = 1; i < K; i++) {
         const double d = logl[i] - logl[0];
         if (fabs(d) > 700.0) zero_acum = true;
-        tmp1 += (d == 0.0) ? 1.0 : exp_(d);          // exp_(0) is exactly 1
+        e[i] = exp_(d);
     }
+#pragma unroll
+    for (int i = 1; i < K; i++) tmp1 += e[i];
     return zero_acum ? 0.0 : 1.0 / tmp1;
 }
 // bayes.cpp:450-477: the component search.  Only the lane that stops the walk needs it (a lane
@@ -290,7 +312,7 @@ __device__ __forceinline__ void decide_rest_wave(int s, double prob, double acum
 #pragma unroll
     for (int j = 1; j < K; j++) { lk = tk == j ? ls[j] : lk; lref = ti1 == j ? ls[j] : lref; }
     const double d = lk - lref;
-    const double e = (d == 0.0) ? 1.0 : exp_(d);                     // exp_(0) is exactly 1
+    const double e = exp_(d);                                        // exp_(0) is exactly 1
     bool zero_inc = false;                                           // of step ti
 #pragma unroll
     for (int j = 1; j < K; j++)
@@ -356,8 +378,8 @@ struct Totals { double t0, t1, t2, t3; };
 #define SSTAMP(i) do { } while (0)
 #endif
 
-template <int K>
-__device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, int G, char* smem, const double* tab,
+template <int K, class TP>
+__device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
                                                   const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
                                                   double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer) {
     const int lane = threadIdx.x & 63;
@@ -387,7 +409,8 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
         const bool act = lane < nbp;
         const int m = in.m, g = in.g;
         const double beta_old = in.beta_old;
-        const bool sig0 = act && (tab[g] == 0.0);                   // bayes.cpp:396-400
+        const LaneTab<K> tb = load_tab<K>(tab, G, g);
+        const bool sig0 = act && (tb.sg == 0.0);                    // bayes.cpp:396-400
         const bool use = act && !sig0;
         const unsigned long long use_mask = __ballot(use);
         const int prefix = __popcll(use_mask & ((1ull << lane) - 1ull));
@@ -400,12 +423,11 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
         double muk[K], logl[K];
 #pragma unroll
         for (int i = 0; i < K; i++) { muk[i] = 0.0; logl[i] = 0.0; }
-        const double* denom_g = tab + G + g * K;
         if (use) {
             const double dpa = tt.t0 + tt.t1, dpb = tt.t2 + tt.t3;
             double num = in.msig * (dpa - in.mave * dpb);               // bayes.cpp:765
             num += beta_old * nm1;                                       // bayes.cpp:421
-            acum_v = decide0<K>(num, denom_g, tab + G + G * K + g * K, tab + G + 2 * G * K + g * K, inv2sige, muk, logl);
+            acum_v = decide0<K>(num, tb, inv2sige, muk, logl);
         }
         SSTAMP(1);   // decide0
         // a lane whose draw exceeds acum0 ends in a component > 0 (bayes.cpp:451,476): it stops the walk
@@ -420,7 +442,7 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
             if (lane == s) {
 #pragma unroll
                 for (int i = 1; i < K; i++)
-                    if (i == kc) { muk_c = muk[i]; denom_c = denom_g[i]; }
+                    if (i == kc) { muk_c = muk[i]; denom_c = tb.denom[i]; }
             }
         }
 
@@ -486,8 +508,8 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
 }
 
 // K = 4 (the reference's example mixtures) is inlined into the kernel; other K share out-of-line copies.
-template <int K>
-__device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, char* smem, const double* tab,
+template <int K, class TP>
+__device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
                                           const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
                                           double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer) {
     sample_batch_body<K>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tot0, tot1, sigmae, inv2sige, nm1, out, writer);
@@ -1206,22 +1228,27 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             PROF(4);   // wait for the totals
             bad |= !okw;
             if (okw) {
-                if (K == 4) {
-                    sample_batch_body<4>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, li_cur0, li_cur1, tot0, tot1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0);
-                } else {
-                    // out-of-line copies take their inputs by address: hand them copies, so that the
-                    // loop-carried lane inputs themselves stay in registers (no scratch round trips)
-                    const LaneIn lc0 = li_cur0, lc1 = li_cur1;
-                    const Totals tc0 = tot0, tc1 = tot1;
-                    switch (K) {
-                        case 2: sample_batch<2>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                        case 3: sample_batch<3>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                        case 5: sample_batch<5>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                        case 6: sample_batch<6>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                        case 7: sample_batch<7>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                        default: sample_batch<8>(cur.nb, BMAX, a.nb_factor16, G, smem, tabp, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                // ONE copy of the step per table address space (only one of them runs in a launch)
+                auto run_step = [&](auto tabq) {
+                    if (K == 4) {
+                        sample_batch_body<4>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0);
+                    } else {
+                        // out-of-line copies take their inputs by address: hand them copies, so that the
+                        // loop-carried lane inputs themselves stay in registers (no scratch round trips)
+                        const LaneIn lc0 = li_cur0, lc1 = li_cur1;
+                        const Totals tc0 = tot0, tc1 = tot1;
+                        switch (K) {
+                            case 2: sample_batch<2>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            case 3: sample_batch<3>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            case 5: sample_batch<5>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            case 6: sample_batch<6>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            case 7: sample_batch<7>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            default: sample_batch<8>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                        }
                     }
-                }
+                };
+                if (tab_in_lds) run_step((TabLds)s_tab);
+                else run_step((TabGlobal)a.sigmag);
             }
         }
         PROF(7);   // sampling step (wavefront 0's own time)
