@@ -95,6 +95,9 @@ SIGNATURES = {
     "gmrm_get_comp": (C.c_int, [VP, C.c_int, c_int_p]),
     "gmrm_get_acum": (C.c_int, [VP, C.c_int, c_double_p]),
     "gmrm_set_betas": (C.c_int, [VP, C.c_int, c_double_p]),
+    "gmrm_set_comp": (C.c_int, [VP, C.c_int, c_int_p]),
+    "gmrm_sampler_save": (C.c_int, [VP, C.c_char_p, C.c_int]),
+    "gmrm_sampler_load": (C.c_int, [VP, C.c_char_p, c_int_p]),
     "gmrm_selftest_math": (C.c_int, [C.c_int, C.c_int, c_double_p, c_double_p, C.c_int]),
     "gmrm_eps_snapshot": (C.c_int, [VP, C.c_int]),
     "gmrm_eps_delta_export": (C.c_int, [VP, C.c_int, VP]),

@@ -326,6 +326,16 @@ class Sampler:
         pi = np.ascontiguousarray(pi_est, dtype=np.float64).reshape(-1)
         check(self.lib.gmrm_sampler_adopt(self.h, int(t), _dp(sg), _dp(pi), float(sigmae)))
 
+    def save(self, path, it):
+        """Checkpoint after iteration `it` (gmrm_sampler_save)."""
+        check(self.lib.gmrm_sampler_save(self.h, str(path).encode(), int(it)))
+
+    def load(self, path) -> int:
+        """Restore a checkpoint; returns the iteration it was written after."""
+        it = C.c_int(0)
+        check(self.lib.gmrm_sampler_load(self.h, str(path).encode(), C.byref(it)))
+        return it.value
+
     def hyper(self, t=0) -> Hyper:
         h = _lib.HyperC()
         check(self.lib.gmrm_sampler_get(self.h, int(t), C.byref(h)))

@@ -702,6 +702,13 @@ int gmrm_get_comp(gmrm_ctx* c, int t, int* comp) {
     HIPCHK(hipMemcpy(comp, c->tr[t].comp, (size_t)c->M * sizeof(int), hipMemcpyDeviceToHost));
     return GMRM_OK;
 }
+int gmrm_set_comp(gmrm_ctx* c, int t, const int* comp) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!comp) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->tr[t].comp, comp, (size_t)c->M * sizeof(int), hipMemcpyHostToDevice));
+    return GMRM_OK;
+}
 int gmrm_get_acum(gmrm_ctx* c, int t, double* acum) {
     if (int r = ctx_check_t(c, t)) return r;
     if (!acum) return fail(GMRM_EINVAL, "null argument");

@@ -10,9 +10,11 @@
 #include "gm_internal.h"
 #include "gm_host.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace {
@@ -28,6 +30,10 @@ struct Chain {                       // class Phenotype, the host-resident part
     double sweep_ms = 0.0;
     bool preshuffled = false;        // midx already holds the NEXT iteration's order (shuffled while the GPU swept)
 };
+
+const char CKP_MAGIC[8] = {'G', 'M', 'R', 'M', 'C', 'K', 'P', '1'};                // checkpoint files (gmrm_sampler_save / _load)
+template <class T> bool put(FILE* f, const T* p, size_t n) { return std::fwrite(p, sizeof(T), n, f) == n; }
+template <class T> bool get(FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n, f) == n; }
 
 }  // namespace
 
@@ -265,6 +271,84 @@ int gmrm_sampler_get(gmrm_sampler* s, int t, gmrm_hyper* out) {
     for (int i = 0; i < s->G * s->K; i++) out->pi_est[i] = c.pi_est[i];
     out->n_updates = c.n_updates; out->n_batches = c.n_batches; out->sweep_device_ms = c.sweep_ms;
     out->n_planned_stops = c.n_planned; out->n_stale_dots = c.n_stale;
+    return GMRM_OK;
+}
+
+// ---- checkpoint / restart (upstream has none -- its outputs are deleted at start, bayes.cpp:323) --
+// Everything the next iteration reads: the residual, effects and components (device), the visit order that the
+// next shuffle permutes in place (phenotype.cpp:314-323), hyper-parameters, both RNG streams.  Little-endian
+// binary: magic, dimensions, iteration, then per phenotype the fields in the order written below.
+int gmrm_sampler_save(gmrm_sampler* s, const char* path, int it) {
+    if (!s || !path) return fail(GMRM_EINVAL, "null argument");
+    gmrm_ctx* ctx = s->ctx;
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return fail(GMRM_EIO, std::string("cannot write checkpoint ") + tmp);
+    const int hdr[12] = {ctx->N, ctx->M, ctx->Mt, ctx->S, ctx->T, s->G, s->K, it, (int)s->seed, s->rank, s->nranks,
+                         s->shuffle * 2 + s->mimic_hydra};
+    bool ok = put(f, CKP_MAGIC, 8) && put(f, hdr, 12);
+    std::vector<double> eps(4 * ctx->mbytes), betas((size_t)std::max(1, ctx->M));
+    std::vector<int> comp((size_t)std::max(1, ctx->M));
+    int rc = GMRM_OK;
+    for (int t = 0; t < ctx->T && ok && rc == GMRM_OK; t++) {
+        const Chain& c = s->ch[t];
+        if ((rc = gmrm_download_eps(ctx, t, eps.data())) != GMRM_OK) break;
+        if (ctx->M > 0) {
+            if ((rc = gmrm_get_betas(ctx, t, betas.data())) != GMRM_OK) break;
+            if ((rc = gmrm_get_comp(ctx, t, comp.data())) != GMRM_OK) break;
+        }
+        const int flags[1] = {c.preshuffled ? 1 : 0};
+        const double sc[3] = {c.sigmae, c.mu, c.epssum};
+        ok = put(f, sc, 3) && put(f, flags, 1) && put(f, c.dist_m.mt, 624) && put(f, &c.dist_m.idx, 1) &&
+             put(f, c.dist_d.mt, 624) && put(f, &c.dist_d.idx, 1) && put(f, c.midx.data(), (size_t)ctx->M) &&
+             put(f, c.m0.data(), (size_t)s->G) && put(f, c.cass.data(), (size_t)s->G * s->K) &&
+             put(f, c.sigmag.data(), (size_t)s->G) && put(f, c.pi_est.data(), (size_t)s->G * s->K) &&
+             put(f, betas.data(), (size_t)ctx->M) && put(f, comp.data(), (size_t)ctx->M) && put(f, eps.data(), eps.size());
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    if (rc != GMRM_OK) { std::remove(tmp.c_str()); return rc; }
+    if (!ok || std::rename(tmp.c_str(), path) != 0) { std::remove(tmp.c_str()); return fail(GMRM_EIO, std::string("short write on checkpoint ") + path); }
+    return GMRM_OK;
+}
+
+int gmrm_sampler_load(gmrm_sampler* s, const char* path, int* it_out) {
+    if (!s || !path || !it_out) return fail(GMRM_EINVAL, "null argument");
+    gmrm_ctx* ctx = s->ctx;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(GMRM_EIO, std::string("cannot open checkpoint ") + path);
+    char magic[8];
+    int hdr[12];
+    bool ok = get(f, magic, 8) && get(f, hdr, 12) && std::memcmp(magic, CKP_MAGIC, 8) == 0;
+    const int want[12] = {ctx->N, ctx->M, ctx->Mt, ctx->S, ctx->T, s->G, s->K, 0, (int)s->seed, s->rank, s->nranks,
+                          s->shuffle * 2 + s->mimic_hydra};
+    for (int i = 0; ok && i < 12; i++)
+        if (i != 7 && hdr[i] != want[i]) { std::fclose(f); return fail(GMRM_EINVAL, "checkpoint was written for other dimensions / options / seed"); }
+    if (!ok) { std::fclose(f); return fail(GMRM_EIO, std::string("not a gmrm checkpoint: ") + path); }
+    std::vector<double> eps(4 * ctx->mbytes), betas((size_t)std::max(1, ctx->M));
+    std::vector<int> comp((size_t)std::max(1, ctx->M));
+    int rc = GMRM_OK;
+    for (int t = 0; t < ctx->T && ok && rc == GMRM_OK; t++) {
+        Chain& c = s->ch[t];
+        int flags[1];
+        double sc[3];
+        ok = get(f, sc, 3) && get(f, flags, 1) && get(f, c.dist_m.mt, 624) && get(f, &c.dist_m.idx, 1) &&
+             get(f, c.dist_d.mt, 624) && get(f, &c.dist_d.idx, 1) && get(f, c.midx.data(), (size_t)ctx->M) &&
+             get(f, c.m0.data(), (size_t)s->G) && get(f, c.cass.data(), (size_t)s->G * s->K) &&
+             get(f, c.sigmag.data(), (size_t)s->G) && get(f, c.pi_est.data(), (size_t)s->G * s->K) &&
+             get(f, betas.data(), (size_t)ctx->M) && get(f, comp.data(), (size_t)ctx->M) && get(f, eps.data(), eps.size());
+        if (!ok) break;
+        c.sigmae = sc[0]; c.mu = sc[1]; c.epssum = sc[2]; c.preshuffled = flags[0] != 0;
+        if ((rc = gmrm_upload_eps(ctx, t, eps.data())) != GMRM_OK) break;
+        if (ctx->M > 0) {
+            if ((rc = gmrm_set_betas(ctx, t, betas.data())) != GMRM_OK) break;
+            if ((rc = gmrm_set_comp(ctx, t, comp.data())) != GMRM_OK) break;
+            c.betas = betas;
+        }
+    }
+    std::fclose(f);
+    if (rc != GMRM_OK) return rc;
+    if (!ok) return fail(GMRM_EIO, std::string("truncated checkpoint ") + path);
+    *it_out = hdr[7];
     return GMRM_OK;
 }
 

@@ -41,6 +41,8 @@ struct Opts {
     int device = 0;
     std::vector<int> devices;     // --devices a,b,...: one marker shard per entry (this build only)
     bool no_rccl = false;
+    unsigned ckp_every = 0;       // --checkpoint-every n: write <out-dir>/gmrm.<shard>.ckp after every n-th iteration (this build only)
+    bool resume = false;          // --resume: continue from those checkpoints instead of starting over (this build only)
 };
 
 [[noreturn]] void fatal(const std::string& m) {
@@ -133,6 +135,8 @@ Opts parse(int argc, char** argv) {
             ss << "--gpus " << n << "\n";
         }
         else if (a == "--no-rccl") { o.no_rccl = true; ss << "--no-rccl 1\n"; }   // this build only: stage the exchange through the host
+        else if (a == "--checkpoint-every") { last(i); positive(i, "--checkpoint-every", 1); o.ckp_every = (unsigned)atoi(argv[++i]); ss << "--checkpoint-every " << o.ckp_every << "\n"; }
+        else if (a == "--resume") { o.resume = true; ss << "--resume 1\n"; }
         else fatal("FATAL: option \"" + a + "\" unknown");
     }
     std::cout << ss.str() << std::endl;
@@ -183,6 +187,10 @@ struct HistFile {                 // xfiles.hpp:14-38 via POSIX pwrite
         unlink(p.c_str());                                        // bayes.cpp:323 delete_output_files
         fd = open(p.c_str(), O_CREAT | O_WRONLY | O_EXCL, 0644);  // MPI_MODE_CREATE|WRONLY|EXCL
         if (fd < 0) fatal("FATAL  : cannot create output file " + p);
+    }
+    void open_existing(const std::string& p) {                    // --resume: records are rewritten in place from the restart point
+        fd = open(p.c_str(), O_WRONLY, 0644);
+        if (fd < 0) fatal("FATAL  : --resume: cannot open the existing output file " + p);
     }
     void put(const void* buf, size_t n, off_t off) {
         if (pwrite(fd, buf, n, off) != (ssize_t)n) fatal("FATAL  : short write on an output file");
@@ -430,6 +438,20 @@ int main(int argc, char** argv) {
         printf("INFO   : Time to compute the markers' statistics: %.2f seconds.\n", now() - ts);
     }
     for (int r = 0; r < nsh; r++) need(gmrm_sampler_init(smps[r]), "gmrm_sampler_init");
+    // Checkpoint / restart (upstream cannot resume: it deletes its outputs at start, bayes.cpp:323)
+    auto ckp_path = [&](int r) { return (opt.out_dir.empty() ? std::string("") : opt.out_dir + "/") + "gmrm." + std::to_string(r) + ".ckp"; };
+    unsigned it_first = 1;
+    if (opt.resume) {
+        int it_ck = -1;
+        for (int r = 0; r < nsh; r++) {
+            int it_r = 0;
+            need(gmrm_sampler_load(smps[r], ckp_path(r).c_str(), &it_r), "gmrm_sampler_load");
+            if (r > 0 && it_r != it_ck) fatal("FATAL  : --resume: the shards' checkpoints are from different iterations");
+            it_ck = it_r;
+        }
+        it_first = (unsigned)it_ck + 1;
+        printf("INFO   : resuming after iteration %d from %s\n", it_ck, ckp_path(0).c_str());
+    }
     gmrm_sampler* smp = smps[0];
     gmrm_group* grp = nullptr;
     if (nsh > 1) {                                                           // replaces the MPI calls of Bayes::process
@@ -448,15 +470,14 @@ int main(int argc, char** argv) {
     std::vector<HistFile> fbet(T), fcpn(T), fcsv(T);
     for (int t = 0; t < T; t++) {
         std::string base = opt.out_dir.empty() ? stems[t] : opt.out_dir + "/" + stems[t];
-        fbet[t].open_fresh(base + ".bet");
-        fcpn[t].open_fresh(base + ".cpn");
-        fcsv[t].open_fresh(base + ".csv");
+        if (opt.resume) { fbet[t].open_existing(base + ".bet"); fcpn[t].open_existing(base + ".cpn"); fcsv[t].open_existing(base + ".csv"); }
+        else { fbet[t].open_fresh(base + ".bet"); fcpn[t].open_fresh(base + ".cpn"); fcsv[t].open_fresh(base + ".csv"); }
     }
     std::vector<double> betas(Mt);
     std::vector<int> comp(Mt);
     std::vector<char> line(50000);                                          // const.hpp:3 LENBUF
     const unsigned Mtot = (unsigned)Mt;
-    for (unsigned it = 1; it <= opt.iterations; it++) {
+    for (unsigned it = it_first; it <= opt.iterations; it++) {
         const double ts = now();
         printf("\n\n@@@ ITERATION %5d\n", it);
         if (grp) need(gmrm_group_iterate(grp, (int)it), "gmrm_group_iterate");
@@ -485,6 +506,8 @@ int main(int argc, char** argv) {
                 fcpn[t].put(&it, 4, oc); fcpn[t].put(comp.data(), (size_t)Mtot * 4, oc + 4);
             }
         }
+        if (opt.ckp_every > 0 && it % opt.ckp_every == 0)
+            for (int r = 0; r < nsh; r++) need(gmrm_sampler_save(smps[r], ckp_path(r).c_str(), (int)it), "gmrm_sampler_save");
         fflush(stdout);
     }
     for (int t = 0; t < T; t++) { close(fbet[t].fd); close(fcpn[t].fd); close(fcsv[t].fd); }

@@ -130,3 +130,25 @@ def read_history(path, dtype):
     its = np.array([struct.unpack_from("<I", raw, 4 + i * rec)[0] for i in range(n)], dtype=np.uint32)
     vals = np.array([np.frombuffer(raw, dtype=dtype, count=Mtot, offset=8 + i * rec) for i in range(n)])
     return Mtot, its, vals
+
+
+def extract_non_zero(path, rec_min, rec_max):
+    """What bin/extract_non_zero_betaAll prints (upstream: example/extract_non_zero_betaAll, binary only): for
+    every saved record r in [rec_min, rec_max] (0-based position in the .bet file, not the stored iteration
+    number) the non-zero effects as (r, marker, beta).  Stops at the last complete record."""
+    import struct
+    out = []
+    with open(path, "rb") as f:
+        head = f.read(4)
+        if len(head) < 4:
+            return out
+        (M,) = struct.unpack("<I", head)
+        for r in range(max(0, int(rec_min)), int(rec_max) + 1):
+            f.seek(4 + r * (4 + 8 * M) + 4)
+            raw = f.read(8 * M)
+            if len(raw) < 8 * M:
+                break
+            beta = np.frombuffer(raw, dtype="<f8")
+            for m in np.flatnonzero(beta):
+                out.append((r, int(m), float(beta[m])))
+    return out

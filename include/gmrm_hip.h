@@ -172,6 +172,7 @@ int gmrm_get_betas(gmrm_ctx* ctx, int t, double* betas);
 int gmrm_get_comp(gmrm_ctx* ctx, int t, int* comp);
 int gmrm_get_acum(gmrm_ctx* ctx, int t, double* acum);
 int gmrm_set_betas(gmrm_ctx* ctx, int t, const double* betas);
+int gmrm_set_comp(gmrm_ctx* ctx, int t, const int* comp);
 
 /* ------------------------------------------------------------------------------------
  * Multi-GPU residual exchange (replaces the per-step MPI_Allgatherv of src/bayes.cpp:
@@ -231,6 +232,13 @@ int gmrm_sampler_adopt(gmrm_sampler* s, int t, const double* sigmag, const doubl
 int gmrm_sampler_get(gmrm_sampler* s, int t, gmrm_hyper* out);
 /* one .csv record of phenotype t as write_ofile_csv formats it (src/xfiles.cpp:17-42) */
 int gmrm_sampler_csv_line(gmrm_sampler* s, int t, int it, char* buf, size_t len);
+/* Checkpoint / restart (no reference counterpart: Bayes::process deletes its outputs at start,
+ * src/bayes.cpp:323, and cannot resume).  gmrm_sampler_save writes, after iteration `it`, everything iteration
+ * it + 1 reads (residual, effects, components, visit order, hyper-parameters, both RNG streams) to `path`;
+ * gmrm_sampler_load restores it into a sampler created with the same data, options and seed and returns the
+ * iteration in *it.  A run resumed this way continues the chain bit for bit. */
+int gmrm_sampler_save(gmrm_sampler* s, const char* path, int it);
+int gmrm_sampler_load(gmrm_sampler* s, const char* path, int* it);
 
 /* ------------------------------------------------------------------------------------
  * Several marker shards in ONE host process (one context + sampler per GPU): the per-sweep

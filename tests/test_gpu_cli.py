@@ -111,3 +111,35 @@ def test_rccl_entry_points_resolve_and_run(gpu):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=str(ROOT),
                        env={**__import__("os").environ, "GMRM_HIP_RUNTIME": "system"})
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("shards", [1, 2])
+def test_cli_checkpoint_and_resume_continue_the_chain_bit_for_bit(gpu, tmp_path, shards):
+    """--checkpoint-every / --resume (upstream cannot restart: bayes.cpp:323 deletes its outputs).
+    6 iterations in one run == 3 iterations + checkpoint, then a second process resuming to 6: the .bet / .cpn /
+    .csv files must be byte-identical (residual, order, hyper-parameters and both RNG streams are restored)."""
+    assert BIN.exists(), "bin/gmrm_hip not built (python __graft_entry__.py)"
+    case = cases.CASE_BY_NAME["ragged"]
+    inp = cases.make_inputs(case)
+    inp["cva"] = np.array([[float(f"{v:.5f}") for v in row] for row in inp["cva"]])
+    phens = _write_inputs(tmp_path, case, inp)
+    base = [str(BIN), "--bed-file", str(tmp_path / "t.bed"), "--dim-file", str(tmp_path / "t.dim"),
+            "--phen-files", ",".join(str(p) for p in phens), "--group-index-file", str(tmp_path / "t.gri"),
+            "--group-mixture-file", str(tmp_path / "t.grm"), "--shuffle-markers", "1", "--seed", str(case.seed)]
+    if shards > 1:
+        base += ["--devices", ",".join(["0"] * shards)]
+    full, part = tmp_path / "full", tmp_path / "part"
+    r = subprocess.run(base + ["--iterations", "6", "--out-dir", str(full)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run(base + ["--iterations", "3", "--out-dir", str(part), "--checkpoint-every", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert all((part / f"gmrm.{k}.ckp").exists() for k in range(shards))
+    r = subprocess.run(base + ["--iterations", "6", "--out-dir", str(part), "--resume"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "resuming after iteration 3" in r.stdout and "@@@ ITERATION     4" in r.stdout and "@@@ ITERATION     3" not in r.stdout
+    for t in range(inp["y"].shape[0]):
+        for ext in ("bet", "cpn", "csv"):
+            assert (full / f"trait{t}.{ext}").read_bytes() == (part / f"trait{t}.{ext}").read_bytes(), f"trait{t}.{ext} differs after the restart"
+    # a checkpoint of another run is refused
+    r = subprocess.run(base[:-1] + [str(case.seed + 1), "--iterations", "6", "--out-dir", str(part), "--resume"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "checkpoint was written for other dimensions" in r.stdout
