@@ -305,47 +305,56 @@ struct DevMt {                                        // a plain mt19937 in regi
 // ---- Bayes::predict (src/bayes.cpp:16-284), SURVEY section 8f-3 ---------------------------------
 // g_i = sum over this block's markers, in marker order, of ((a - mave) * b * na * msig) * beta_m
 // (bayes.cpp:113-122; the "transposed" use of the genotype table).  Thread = 8 individuals kept in
-// registers for the whole pass; markers with a zero mean effect add +-0 and are skipped.
+// registers for the whole pass; markers with a zero mean effect add +-0 and are skipped.  The four
+// values a marker can add (one per genotype code, computed exactly as the reference's expression) are
+// staged in LDS per chunk of U markers and picked by code with ONE ds_read per individual: the 4-way
+// register select it replaces cost 6 v_cndmask per individual and made the kernel VALU-bound
+// (233 GB/s at 500k x 1M; profiles/README.md).
 __global__ __launch_bounds__(256) void k_predict_g(const uint8_t* __restrict__ bed, const uint8_t* __restrict__ namask2,
                                                    size_t stride, int M, const double* __restrict__ mave,
                                                    const double* __restrict__ msig, const double* __restrict__ beta,
                                                    double* __restrict__ g) {
+    constexpr int U = 32;                                           // column words in flight per thread (HBM latency)
+    __shared__ double s_tv[2][U][4];                                // [chunk parity][marker of the chunk][genotype code]
+    __shared__ int s_nz[2][U];
     const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;          // 2-byte word of every column (8 individuals)
-    if (w * 2 >= stride) return;
-    const uint32_t nam = reinterpret_cast<const uint16_t*>(namask2)[w];
+    const bool live = w * 2 < stride;                                 // (threads beyond the column still help with the tables)
+    const uint32_t nam = live ? reinterpret_cast<const uint16_t*>(namask2)[w] : 0u;
     const uint32_t keep = nam, force = ~nam & 0x5555u;
     double acc[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) acc[i] = 0.0;
-    constexpr int U = 32;                                           // column words in flight per thread (HBM latency)
-    for (int m0 = 0; m0 < M; m0 += U) {
+    int par = 0;
+    for (int m0 = 0; m0 < M; m0 += U, par ^= 1) {
         uint32_t wd[U];
-        double bm[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int m = m0 + u < M ? m0 + u : M - 1;
-            bm[u] = m0 + u < M ? beta[m] : 0.0;
-            wd[u] = reinterpret_cast<const uint16_t*>(bed + (size_t)m * stride)[w];
+            wd[u] = live ? reinterpret_cast<const uint16_t*>(bed + (size_t)m * stride)[w] : 0u;
         }
+        if (threadIdx.x < U * 4) {                                  // one (marker, code) entry per thread
+            const int u = threadIdx.x >> 2, c = threadIdx.x & 3;
+            const int m = m0 + u;
+            const double bm = m < M ? beta[m] : 0.0;
+            double tv = 0.0;
+            if (bm != 0.0) tv = (((code_a(c) - mave[m]) * code_b(c)) * msig[m]) * bm;
+            s_tv[par][u][c] = tv;
+            if (c == 0) s_nz[par][u] = bm != 0.0;
+        }
+        __syncthreads();                                            // one barrier per chunk: the other parity is free by now
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            if (bm[u] != 0.0) {                                      // wave-uniform
-                const int m = m0 + u;
-                const double av = mave[m], sg = msig[m];
-                double tv[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) tv[c] = (((code_a(c) - av) * code_b(c)) * sg) * bm[u];
+            if (s_nz[par][u]) {                                     // uniform over the workgroup
                 const uint32_t x = (wd[u] & keep) | force;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint32_t c = (x >> (2 * i)) & 3u;
-                    acc[i] += c == 0 ? tv[0] : (c == 1 ? tv[1] : (c == 2 ? tv[2] : tv[3]));
-                }
+                for (int i = 0; i < 8; i++) acc[i] += s_tv[par][u][(x >> (2 * i)) & 3u];
             }
         }
     }
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) g[8 * w + i] = acc[i];
+        for (int i = 0; i < 8; i++) g[8 * w + i] = acc[i];
+    }
 }
 
 // Per marker: xtx = sum (a*b*na)^2 (an integer: #(a=1) + 4 #(a=2)), xty = sum a*b*na*y_i

@@ -141,5 +141,7 @@ def test_cli_checkpoint_and_resume_continue_the_chain_bit_for_bit(gpu, tmp_path,
         for ext in ("bet", "cpn", "csv"):
             assert (full / f"trait{t}.{ext}").read_bytes() == (part / f"trait{t}.{ext}").read_bytes(), f"trait{t}.{ext} differs after the restart"
     # a checkpoint of another run is refused
-    r = subprocess.run(base[:-1] + [str(case.seed + 1), "--iterations", "6", "--out-dir", str(part), "--resume"], capture_output=True, text=True, timeout=300)
+    other = list(base)
+    other[other.index("--seed") + 1] = str(case.seed + 1)
+    r = subprocess.run(other + ["--iterations", "6", "--out-dir", str(part), "--resume"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "checkpoint was written for other dimensions" in r.stdout
