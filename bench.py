@@ -271,7 +271,7 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (it cannot
         # be read inside this process); the committed summary of the same workload is quoted.
         traffic = None
-        pmc = ROOT / "profiles" / "r01_v32_pmc_summary.json"
+        pmc = ROOT / "profiles" / "r02_pmc_summary.json"
         if pmc.exists() and a.workload == "c3" and world == 1 and not a.markers and not a.individuals:
             try:
                 traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_k_sweep"]
@@ -293,8 +293,8 @@ def main():
                        "phenotype_na_rate": na_rate, "genotype_missing_rate": miss},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_note": "bytes per launch: raw FETCH_SIZE + WRITE_SIZE from profiles/r01_v32_pmc_summary.json "
-                                         "(separate rocprofv3 --pmc passes of this workload)" if traffic else None,
+                         "traffic_note": "bytes per launch: 2 x FETCH_SIZE (the gfx950 correction for 16-B/lane loads) + WRITE_SIZE from "
+                                         "profiles/r02_pmc_summary.json (separate rocprofv3 --pmc passes of this workload)" if traffic else None,
                          "kernel": "gm::k_sweep (persistent marker loop)",
                          "kernel_ms_avg": avg_kernel_s * 1e3,
                          "kernel_ms_per_launch": kern_ms, "kernel_ms_warmup_launches": warm_ms,
