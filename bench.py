@@ -38,7 +38,11 @@ WORKLOADS = {
     "c3": (500_000, 1_000_000, 1, 1, 0.0, 0.0),
     "c4": (500_000, 1_000_000, 4, 1, 0.0, 0.0),
     "c5": (500_000, 1_000_000, 1, 24, 0.05, 0.05),
+    # not a BASELINE configuration: c3 with missing genotypes (0.1 % of the calls) in 1 % of the markers only -- what the
+    # per-batch choice of the exchange layout is for; compare its rate with c3's
+    "c6": (500_000, 1_000_000, 1, 1, 0.0, 0.001),
 }
+DIRTY_MARKER_FRACTION = {"c6": 0.01}   # workloads whose missing genotypes sit in this fraction of the markers only
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 CPU_THREADS = 1
 
@@ -205,8 +209,19 @@ def main():
 
     t_setup = time.perf_counter()
     ctx = gmrm_amd.Context(N, M, Mt=Mt, S=S, T=T, device=local)
-    ctx.synth_bed(a.seed, 0.4, miss)
+    dirty_frac = DIRTY_MARKER_FRACTION.get(a.workload, 0.0)
+    ctx.synth_bed(a.seed, 0.4, 0.0 if dirty_frac else miss)
     rng = np.random.default_rng(a.seed)
+    if dirty_frac:                                               # code 01 (missing) in `miss` of the calls of the first markers
+        nd = max(1, int(M * dirty_frac))
+        cols = ctx.download_bed(0, nd)
+        per = max(1, int(N * miss))
+        who = rng.integers(0, N, size=(nd, per))
+        rows = np.repeat(np.arange(nd), per)
+        byte, sh = (who // 4).ravel(), (2 * (who % 4)).ravel().astype(np.uint8)
+        cols[rows, byte] = (cols[rows, byte] & ~(np.uint8(3) << sh)) | (np.uint8(1) << sh)
+        ctx.upload_bed(cols, 0)
+        del cols, who, rows, byte, sh
     traits = []
     for t in range(T):
         y = rng.normal(size=N)
@@ -290,7 +305,8 @@ def main():
             "config": {"workload": f"{a.workload}: {N} individuals x {Mt} SNPs, {T} phenotype(s), {G} group(s), "
                                    f"K=4, genotypes Binomial(2,0.4) generated on device, y~N(0,1), seed {a.seed}",
                        "markers_per_gpu": M, "parallelism": f"marker-shard x{world}, 1 residual all-reduce/sweep",
-                       "phenotype_na_rate": na_rate, "genotype_missing_rate": miss},
+                       "phenotype_na_rate": na_rate, "genotype_missing_rate": miss,
+                       "markers_with_missing_genotypes": dirty_frac if dirty_frac else (1.0 if miss > 0 else 0.0)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "bytes per launch: 2 x FETCH_SIZE (the gfx950 correction for 16-B/lane loads) + WRITE_SIZE from "
@@ -307,6 +323,7 @@ def main():
             "sweep": {"updates_per_sweep": upd, "sync_rounds_per_sweep": batches,
                       "update_fraction": [u / float(M) for u in upd],
                       "planned_stops_per_sweep": planned, "stale_dots_per_sweep": stale,
+                      "fast_layout_batches_last_sweep": smp.hyper(0).n_fast_batches,
                       "note": "a round = one batch of dots + one grid-wide exchange; it ends at the first marker whose effect "
                               "changes.  planned stops: the marker was in the model before the visit (known in advance, the batch "
                               "ends there); stale dots: computed behind an unplanned stop and thrown away"},

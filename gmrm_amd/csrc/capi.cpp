@@ -562,7 +562,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.N = c->N; a.M = c->M; a.W = c->W; a.Wpad = c->Wpad; a.G = G; a.K = K;
     a.stride = c->stride;
     a.bed = c->bed; a.namask2 = tr.namask2; a.order = tr.order; a.group = c->group;
-    a.mave = tr.mave; a.msig = tr.msig;
+    a.mave = tr.mave; a.msig = tr.msig; a.nomiss = tr.nomiss;
     a.betas_in = tr.betas[tr.cur]; a.betas_out = tr.betas[tr.cur ^ 1];
     a.comp = tr.comp; a.acum = tr.acum; a.eps = tr.eps;
     a.sigmag = tr.tab; a.denom = tr.tab + G; a.logpi = tr.tab + G + (size_t)G * K; a.mhl = tr.tab + G + 2 * (size_t)G * K;
@@ -620,7 +620,7 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
     if (!tr.in_flight) return fail(GMRM_ESTATE, "no sweep in flight for this phenotype");
     tr.in_flight = false;
     if (tr.empty) {
-        if (out) { out->n_updates = 0; out->n_batches = 0; out->device_ms = 0.0; out->n_planned_stops = 0; out->n_stale_dots = 0;
+        if (out) { out->n_updates = 0; out->n_batches = 0; out->device_ms = 0.0; out->n_planned_stops = 0; out->n_stale_dots = 0; out->n_fast_batches = 0;
                    if (out->cass) std::memset(out->cass, 0, sizeof(int) * (size_t)tr.G * tr.K); }
         return GMRM_OK;
     }
@@ -649,6 +649,7 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
         long long st[40];
         HIPCHK(hipMemcpy(st, tr.stats, sizeof(st), hipMemcpyDeviceToHost));
         out->n_updates = st[0]; out->n_batches = st[1]; out->n_planned_stops = st[29]; out->n_stale_dots = st[30];
+        out->n_fast_batches = st[31];
         if (const char* path = std::getenv("GMRM_SWEEP_TRACE")) {
             if (tr.trace) {
                 std::vector<unsigned long long> h((size_t)256 * 64 * 8);

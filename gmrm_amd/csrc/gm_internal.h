@@ -24,6 +24,7 @@ struct SweepArgs {
     const int* group;              // [M] group of each local marker
     const double* mave;            // [M]
     const double* msig;            // [M]
+    const uint8_t* nomiss;         // [M] 1: the marker has no missing genotype among the phenotyped individuals
     const double* betas_in;        // [M] effects before this sweep
     double* betas_out;             // [M] effects after this sweep
     int* comp;                     // [M]

@@ -96,7 +96,8 @@ constexpr int TAB_LDS = 320;                    // group tables up to 320 double
 constexpr int L_TAB  = L_SUM + SW_VMAX * 8;     // double[TAB_LDS] per-group tables
 constexpr int META_POS = 256;                   // per-marker inputs of the sampling step, ring over order positions
 constexpr int L_META = L_TAB + TAB_LDS * 8;     // int m[256], int g[256], double beta[256], mave[256], msig[256]
-constexpr int L_TOT  = L_META + META_POS * 32;  // double[SW_VMAX]: the batch totals as wavefront 0 fetched them
+constexpr int L_NM   = L_META + META_POS * 32;  // uint8[256]: "no missing genotype" flag of the marker at each ring position
+constexpr int L_TOT  = L_NM + META_POS;         // double[SW_VMAX]: the batch totals as wavefront 0 fetched them
 constexpr int L_PLN  = L_TOT + SW_VMAX * 8;     // uint8[8][PSTRIDE]: digit planes of the residual (operand B order)
 template <int R> constexpr int l_ring() { return L_PLN + Geo<R>::PLANES; }
 static_assert(L_PLN % 16 == 0, "LDS carve");
@@ -672,8 +673,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     constexpr int PST = GE::PSTRIDE;                 // bytes per digit plane
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wg = blockIdx.x;
     const int W = a.W, K = a.K, G = a.G;
-    constexpr bool fast = FAST;                      // exchange layout, fixed per launch (host: all_nomiss)
-    const int BMAX = fast ? GE::BMAXF : GE::BMAXG;
+    // FAST: every marker of the block is free of missing genotypes among the phenotyped individuals (host:
+    // all_nomiss) -- every batch uses the 2-value exchange layout and the general code is not even compiled in.
+    // Otherwise the layout is chosen PER BATCH from the markers' flags: a batch is a run of markers of one kind.
+    const int BMAX = GE::BMAXF;                      // cap of the batch-size estimate (a general batch is cut to BMAXG)
 
     const double* s_val = reinterpret_cast<const double*>(smem + L_VAL);
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
@@ -686,7 +689,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     double* s_tab = reinterpret_cast<double*>(smem + L_TAB);
     char* planes = smem + L_PLN;
     const bool tab_in_lds = G * (1 + 3 * K) <= TAB_LDS;
-    const double* tabp = tab_in_lds ? s_tab : a.sigmag;   // sigmag|denom|logpi|mhl, contiguous
     char* ring = smem + l_ring<R>();
     unsigned* abort_word = a.cnt + 64;
     const unsigned long long spin_limit = a.spin_ticks;
@@ -897,8 +899,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     double* mr_beta = reinterpret_cast<double*>(mr_g + META_POS);
     double* mr_mave = mr_beta + META_POS;
     double* mr_msig = mr_mave + META_POS;
+    uint8_t* mr_nm = reinterpret_cast<uint8_t*>(smem + L_NM);
     int mhi = 0, npm = 0;                             // meta ring holds positions [pos, mhi)
-    int pm_m[2] = {0, 0}, pm_g[2] = {0, 0};
+    int pm_m[2] = {0, 0}, pm_g[2] = {0, 0}, pm_nm[2] = {1, 1};
     double pm_beta[2] = {0.0, 0.0}, pm_mave[2] = {0.0, 0.0}, pm_msig[2] = {1.0, 1.0};
     auto meta_issue = [&](int want) {
         if (want > a.M) want = a.M;
@@ -916,6 +919,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     pm_beta[h] = a.betas_in[pm_m[h]];
                     pm_mave[h] = a.mave[pm_m[h]];
                     pm_msig[h] = a.msig[pm_m[h]];
+                    if (!FAST) pm_nm[h] = a.nomiss[pm_m[h]];
                 }
             }
         }
@@ -930,6 +934,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 if (64 * h + lane < nc) {
                     const int sl = (mhi + 64 * h + lane) & (META_POS - 1);
                     mr_m[sl] = pm_m[h]; mr_g[sl] = pm_g[h]; mr_beta[sl] = pm_beta[h]; mr_mave[sl] = pm_mave[h]; mr_msig[sl] = pm_msig[h];
+                    if (!FAST) mr_nm[sl] = (uint8_t)pm_nm[h];
                 }
             }
         }
@@ -948,9 +953,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // the reducers); otherwise it is discarded and a fresh batch starts after the stopping
     // marker.  Generation g uses tag g+1 and buffer g&1; a buffer is rewritten only after every
     // workgroup has sampled the generation that used it.
-    struct Batch { int p0, nb, nv; unsigned gen; bool planned; };   // planned: ends at a marker known to stop the walk
+    struct Batch { int p0, nb, nv; unsigned gen; bool planned, fast; };   // planned: ends at a marker known to stop the walk; fast: 2-value layout
     unsigned gen_next = 0;
-    long long n_upd = 0, n_batch = 0, n_disc = 0, n_planned = 0, n_stale = 0;
+    long long n_upd = 0, n_batch = 0, n_disc = 0, n_planned = 0, n_stale = 0, n_fastb = 0;
     int max_nb = 0;
     bool ok = true;
 #ifdef GM_SWEEP_PROF
@@ -970,6 +975,21 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         lds_barrier();                                // ring / plane / meta writes are visible (no vmcnt drain)
         PA(0);
         const int p0 = b.p0;
+        // Exchange layout of this batch: a run of markers of ONE kind -- without missing genotypes (2 values per
+        // marker + 2 per batch) or with (4 per marker, at most BMAXG of them).  The batch ends before the first
+        // marker of the other kind.  (Every wavefront scans the same LDS bytes: uniform.)
+        bool bfast = FAST;
+        if (!FAST) {
+            const bool kind = mr_nm[p0 & (META_POS - 1)] != 0;
+            const bool d0 = lane < b.nb && (mr_nm[(p0 + lane) & (META_POS - 1)] != 0) != kind;
+            const bool d1 = lane + 64 < b.nb && (mr_nm[(p0 + lane + 64) & (META_POS - 1)] != 0) != kind;
+            const unsigned long long k0 = __ballot(d0), k1 = __ballot(d1);
+            const int cut = k0 ? __ffsll((long long)k0) - 1 : (k1 ? 64 + __ffsll((long long)k1) - 1 : b.nb);
+            if (cut < b.nb) b.nb = cut;               // cut >= 1: position 0 is of its own kind
+            if (!kind && b.nb > GE::BMAXG) b.nb = GE::BMAXG;
+            bfast = kind;
+        }
+        b.fast = bfast;
         // A marker whose effect is non-zero always changes it (bayes.cpp:479-483: the new draw differs), so
         // the walk is known to stop there: end the batch at the first such marker instead of computing dots
         // behind it that are certain to go stale.  (Every wavefront scans the same LDS words: uniform.)
@@ -1006,9 +1026,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // One pass = ONE or TWO tiles of 16 markers (t and t + tsplit: operand B is read once for both) x NS
         // super-steps of the slice starting at ss_lo.  NS and the tile count are compile-time so that the body is
         // ONE basic block; the LDS reads of super-step s + 1 are in flight during the arithmetic of s.
-        auto tile_pass = [&](auto ns_tag, auto nt_tag, int t) {
+        auto tile_pass = [&](auto ns_tag, auto nt_tag, auto fast_tag, int t) {
             constexpr int NS = decltype(ns_tag)::value;
             constexpr int NTL = decltype(nt_tag)::value;              // tiles in this pass
+            constexpr bool TF = decltype(fast_tag)::value;            // this batch's layout: no missing genotypes
             uint32_t sl0[NTL];
             int swz[NTL];
 #pragma unroll
@@ -1048,7 +1069,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     acc1[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc1[q], 0, 0, 0);
                     acc2[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc2[q], 0, 0, 0);
                     acc0[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, b3, acc0[q], 0, 0, 0);
-                    if (!FAST) {
+                    if (!TF) {
                         // 1 in the low bit of every field that reads 11 (missing): field & (field >> 1)
                         const u32x4 u = {w.x & (w.x >> 1), w.y & (w.y >> 1), w.z & (w.z >> 1), w.w & (w.w >> 1)};
                         const v4i z0 = {(int)(u.x & M1), (int)(u.y & M1), (int)(u.z & M1), (int)(u.w & M1)};
@@ -1073,7 +1094,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     const int m = 16 * (t + q * tsplit) + 4 * kg + r;
                     const int x = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);   // sum c' * digit (c' = a wherever the residual is not 0)
                     const long long sx = quad_sum64((long long)x << (8 * (n & 3)));
-                    if (FAST) {
+                    if (TF) {
                         if ((n & 3) == 0 && n < 8 && m < nb) atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)sx);
                     } else {
                         // a = c' - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
@@ -1090,22 +1111,27 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         };
         using IC1 = std::integral_constant<int, 1>;
         using IC2 = std::integral_constant<int, 2>;
-        if (ksplit == 1) {                            // four or more tiles: every wavefront walks whole slices, two tiles at a time
+        auto tiles = [&](auto fast_tag) {
+            if (ksplit == 1) {                        // four or more tiles: every wavefront walks whole slices, two tiles at a time
 #pragma unroll 1
-            for (int t = wt; t < nt; t += 8) {
-                if (t + 4 < nt) tile_pass(std::integral_constant<int, SS>{}, IC2{}, t);    // tiles t and t + 4 share operand B
-                else tile_pass(std::integral_constant<int, SS>{}, IC1{}, t);
-            }
-        } else {                                      // fewer tiles than wavefronts: the slice is split ksplit ways
+                for (int t = wt; t < nt; t += 8) {
+                    if (t + 4 < nt) tile_pass(std::integral_constant<int, SS>{}, IC2{}, fast_tag, t);    // tiles t and t + 4 share operand B
+                    else tile_pass(std::integral_constant<int, SS>{}, IC1{}, fast_tag, t);
+                }
+            } else {                                  // fewer tiles than wavefronts: the slice is split ksplit ways
 #pragma unroll 1
-            for (int t = wt; t < nt; t += tsplit) {
-                if (ksplit == 2) tile_pass(std::integral_constant<int, SS / 2>{}, IC1{}, t);
-                else tile_pass(std::integral_constant<int, SS / 4>{}, IC1{}, t);
+                for (int t = wt; t < nt; t += tsplit) {
+                    if (ksplit == 2) tile_pass(std::integral_constant<int, SS / 2>{}, IC1{}, fast_tag, t);
+                    else tile_pass(std::integral_constant<int, SS / 4>{}, IC1{}, fast_tag, t);
+                }
             }
-        }
+        };
+        if constexpr (FAST) tiles(std::true_type{});
+        else { if (bfast) tiles(std::true_type{}); else tiles(std::false_type{}); }
         PA(2);
         lds_barrier();                                // the LDS sums are complete (prefetches stay in flight)
         PA(3);
+        const bool fast = bfast;
         const int nv = fast ? 2 * nb + 2 : 4 * nb;
         if (tid < nv) {
             double tot;
@@ -1156,7 +1182,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         return bad;
     };
 
-    Batch cur{0, 0, 0, 0u, false}, nxt{0, 0, 0, 0u, false}, tb{0, 0, 0, 0u, false};
+    Batch cur{0, 0, 0, 0u, false, FAST}, nxt{0, 0, 0, 0u, false, FAST}, tb{0, 0, 0, 0u, false, FAST};
     LaneIn li_cur0{0, 0, 0.0, 0.0, 1.0}, li_cur1{0, 0, 0.0, 0.0, 1.0}, li_nxt0{0, 0, 0.0, 0.0, 1.0}, li_nxt1{0, 0, 0.0, 0.0, 1.0};
     bool bad = false;
     {
@@ -1222,7 +1248,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
             Totals tot0{0.0, 0.0, 0.0, 0.0}, tot1{0.0, 0.0, 0.0, 0.0};
-            const bool okw = poll_totals(cur.nb, fast, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word, spin_limit);
+            const bool okw = poll_totals(cur.nb, cur.fast, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word, spin_limit);
             if (lane == 0) *reinterpret_cast<volatile int*>(&ctl[C_TOTF]) = (int)(cur.gen + 1u);   // the loaders may start
             TRACE(3);
             PROF(4);   // wait for the totals
@@ -1268,6 +1294,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         const int n_done = ctl[C_NDONE];
         const bool upd = ctl[C_UPD] != 0;
         n_planned += ctl[C_PLN];
+        n_fastb += cur.fast ? 1 : 0;
         n_stale += cur.nb - n_done;                   // dots computed behind the stop: thrown away
         if (upd) {
             n_upd++;
@@ -1322,7 +1349,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (tid == 0) {
             *a.rng_index = ctl[C_CURSOR];
             a.stats[0] = n_upd; a.stats[1] = n_batch; a.stats[2] = max_nb; a.stats[3] = n_disc;
-            a.stats[29] = n_planned; a.stats[30] = n_stale;
+            a.stats[29] = n_planned; a.stats[30] = n_stale; a.stats[31] = n_fastb;
         }
     }
 #ifdef GM_SWEEP_PROF
