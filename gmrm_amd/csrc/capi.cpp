@@ -583,6 +583,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.nb_factor16 = c->nb_factor16;
     a.spec_factor16 = c->spec_factor16;
     a.all_nomiss = tr.all_nomiss;
+    if (std::getenv("GMRM_FORCE_MIXED")) a.all_nomiss = 0;    // diagnostic: run a clean block through the per-marker-layout kernel
     a.spin_ticks = (unsigned long long)c->spin_timeout_ms * 100000ull;      // s_memrealtime ticks (100 MHz)
     // Phenotypes that do not fit side by side share stream 0 and run one after another.
     hipStream_t st = c->tr[t % c->conc].stream;       // conc chains side by side, the others queue behind them

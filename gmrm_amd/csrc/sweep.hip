@@ -68,7 +68,6 @@ template <int R> struct Geo {
     static constexpr int CPP = SB / 16;                   // 16-byte chunks per position
     static constexpr int RPOS = R == 4 ? 96 : 240;        // ring capacity in order positions
     static constexpr int BMAXF = RPOS / 2;                // markers per batch, no-missing layout (2 values/marker)
-    static constexpr int BMAXG = RPOS / 2 < 64 ? RPOS / 2 : 64;   // general layout (4 values/marker <= SW_VMAX)
     static constexpr int NL = 192;                        // loader threads (wavefronts 1-3)
     static constexpr int PPI = NL / CPP;                  // positions covered by one load instruction
     static constexpr int PFG = 4;                         // loads per wave-uniform branch
@@ -79,7 +78,7 @@ template <int R> struct Geo {
     static constexpr int PSTRIDE = 4 * SB + 16;
     static constexpr int PLANES = 8 * PSTRIDE + 64;       // bytes of the eight planes
     static_assert(NL % CPP == 0 && PPI >= 1, "loader mapping");
-    static_assert(2 * BMAXF + 2 <= SW_VMAX && 4 * BMAXG <= SW_VMAX, "exchange rows");
+    static_assert(2 * BMAXF + 2 <= SW_VMAX, "exchange rows");
 };
 
 // ---- LDS carve (bytes, all multiples of 16) --------------------------------------------
@@ -358,10 +357,13 @@ struct LaneIn {
     int m, g;
     double beta_old, mave, msig;
 };
-// Exchange layouts.  General: 4 values per marker (sum a*q1, a*q2, b*q1, b*q2).  Fast (no marker
-// of the batch has a missing genotype among the phenotyped individuals, so b == 1 wherever the
-// residual is non-zero): 2 values per marker (sum a*q1, a*q2) + 2 per batch (sum q1, sum q2 over
-// all individuals = the b-sums of every such marker).
+// Exchange layout of a batch of nb markers, nd of which have a missing genotype among the phenotyped individuals
+// ("dirty": the per-marker flag comes from the marker statistics):
+//   [2 p], [2 p + 1]                    sum a q1, sum a q2 of batch position p            (every marker)
+//   [2 nb], [2 nb + 1]                  sum q1, sum q2 over all individuals = the b-sums of every clean marker
+//   [2 nb + 2 + 2 r], [.. + 1]          sum b q1, sum b q2 of the r-th dirty marker of the batch
+// 2 nb + 2 + 2 nd <= SW_VMAX values: a block without missing genotypes exchanges 2 per marker (batches of up to
+// 120), one with missing genotypes everywhere 4 per marker (63), anything in between pays per dirty marker.
 struct SampleOut {                 // global outputs, written by workgroup 0 only
     double* acum;
     double* betas_out;
@@ -516,15 +518,23 @@ __device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, c
     sample_batch_body<K>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tot0, tot1, sigmae, inv2sige, nm1, out, writer);
 }
 
+// rank of batch position p among the dirty markers of the batch (dm0: positions 0..63, dm1: 64..127)
+__device__ __forceinline__ int dirty_rank(unsigned long long dm0, unsigned long long dm1, int p) {
+    return p < 64 ? __popcll(dm0 & ((1ull << p) - 1ull)) : __popcll(dm0) + __popcll(dm1 & ((1ull << (p - 64)) - 1ull));
+}
+__device__ __forceinline__ bool dirty_at(unsigned long long dm0, unsigned long long dm1, int p) {
+    return ((p < 64 ? dm0 >> p : dm1 >> (p - 64)) & 1ull) != 0ull;
+}
+
 // Wavefront 0 fetches ALL totals of the generation with four 16-byte loads per lane (whole cache
 // lines, one round trip per look, ~6x fewer requests to the one hot 4 KB region than per-marker
 // polling), parks them in LDS and lane j picks the values of batch positions j and 64 + j.
 // Returns false on timeout.
-__device__ __forceinline__ bool poll_totals(int nb, bool fast, const unsigned long long* Ttg, unsigned tag, char* smem,
+__device__ __forceinline__ bool poll_totals(int nb, int nv, unsigned long long dm0, unsigned long long dm1,
+                                            const unsigned long long* Ttg, unsigned tag, char* smem,
                                             Totals& tot0, Totals& tot1, unsigned* abort_word, unsigned long long spin_limit) {
     const int lane = threadIdx.x & 63;
     double* s_tot = reinterpret_cast<double*>(smem + L_TOT);
-    const int nv = fast ? 2 * nb + 2 : 4 * nb;
     Spin sp;
     sp.start(spin_limit);
     bool bad = false;
@@ -542,13 +552,17 @@ __device__ __forceinline__ bool poll_totals(int nb, bool fast, const unsigned lo
     for (int k = 0; k < 4; k++)
         s_tot[64 * k + lane] = __longlong_as_double((long long)(((unsigned long long)d[k].z << 32) | d[k].x));
     Totals t0{0.0, 0.0, 0.0, 0.0}, t1{0.0, 0.0, 0.0, 0.0};
-    if (fast) {
-        const double sq1 = s_tot[2 * nb], sq2 = s_tot[2 * nb + 1];
-        if (lane < nb) t0 = Totals{s_tot[2 * lane], s_tot[2 * lane + 1], sq1, sq2};
-        if (lane + 64 < nb) t1 = Totals{s_tot[2 * lane + 128], s_tot[2 * lane + 129], sq1, sq2};
-    } else {
-        if (lane < nb) t0 = Totals{s_tot[4 * lane], s_tot[4 * lane + 1], s_tot[4 * lane + 2], s_tot[4 * lane + 3]};
+    const double sq1 = s_tot[2 * nb], sq2 = s_tot[2 * nb + 1];
+    if (lane < nb) {
+        const int zs = dirty_at(dm0, dm1, lane) ? 2 * nb + 2 + 2 * dirty_rank(dm0, dm1, lane) : 2 * nb;
+        t0 = Totals{s_tot[2 * lane], s_tot[2 * lane + 1], s_tot[zs], s_tot[zs + 1]};
     }
+    if (lane + 64 < nb) {
+        const int p = lane + 64;
+        const int zs = dirty_at(dm0, dm1, p) ? 2 * nb + 2 + 2 * dirty_rank(dm0, dm1, p) : 2 * nb;
+        t1 = Totals{s_tot[2 * p], s_tot[2 * p + 1], s_tot[zs], s_tot[zs + 1]};
+    }
+    (void)sq1; (void)sq2;
     tot0 = t0; tot1 = t1;
     return !__any(bad);
 }
@@ -674,9 +688,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wg = blockIdx.x;
     const int W = a.W, K = a.K, G = a.G;
     // FAST: every marker of the block is free of missing genotypes among the phenotyped individuals (host:
-    // all_nomiss) -- every batch uses the 2-value exchange layout and the general code is not even compiled in.
-    // Otherwise the layout is chosen PER BATCH from the markers' flags: a batch is a run of markers of one kind.
-    const int BMAX = GE::BMAXF;                      // cap of the batch-size estimate (a general batch is cut to BMAXG)
+    // all_nomiss) -- 2 exchanged values per marker and the code for missing genotypes is not even compiled in.
+    // Otherwise the markers' flags decide per marker (2 more values) and per tile of 16 (a second MFMA set).
+    const int BMAX = GE::BMAXF;                      // cap of the batch-size estimate (dirty markers shorten a batch: 2 more slots each)
 
     const double* s_val = reinterpret_cast<const double*>(smem + L_VAL);
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
@@ -953,7 +967,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // the reducers); otherwise it is discarded and a fresh batch starts after the stopping
     // marker.  Generation g uses tag g+1 and buffer g&1; a buffer is rewritten only after every
     // workgroup has sampled the generation that used it.
-    struct Batch { int p0, nb, nv; unsigned gen; bool planned, fast; };   // planned: ends at a marker known to stop the walk; fast: 2-value layout
+    struct Batch { int p0, nb, nv; unsigned gen; bool planned; unsigned long long dm0, dm1; };   // planned: ends at a marker known to stop the walk; dm: dirty positions
     unsigned gen_next = 0;
     long long n_upd = 0, n_batch = 0, n_disc = 0, n_planned = 0, n_stale = 0, n_fastb = 0;
     int max_nb = 0;
@@ -975,21 +989,19 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         lds_barrier();                                // ring / plane / meta writes are visible (no vmcnt drain)
         PA(0);
         const int p0 = b.p0;
-        // Exchange layout of this batch: a run of markers of ONE kind -- without missing genotypes (2 values per
-        // marker + 2 per batch) or with (4 per marker, at most BMAXG of them).  The batch ends before the first
-        // marker of the other kind.  (Every wavefront scans the same LDS bytes: uniform.)
-        bool bfast = FAST;
+        // Dirty markers (a missing genotype among the phenotyped individuals) exchange two more values each: the batch
+        // is cut where the slots run out.  (Every wavefront reads the same LDS bytes: uniform.)
+        unsigned long long dm0 = 0ull, dm1 = 0ull;
         if (!FAST) {
-            const bool kind = mr_nm[p0 & (META_POS - 1)] != 0;
-            const bool d0 = lane < b.nb && (mr_nm[(p0 + lane) & (META_POS - 1)] != 0) != kind;
-            const bool d1 = lane + 64 < b.nb && (mr_nm[(p0 + lane + 64) & (META_POS - 1)] != 0) != kind;
-            const unsigned long long k0 = __ballot(d0), k1 = __ballot(d1);
-            const int cut = k0 ? __ffsll((long long)k0) - 1 : (k1 ? 64 + __ffsll((long long)k1) - 1 : b.nb);
-            if (cut < b.nb) b.nb = cut;               // cut >= 1: position 0 is of its own kind
-            if (!kind && b.nb > GE::BMAXG) b.nb = GE::BMAXG;
-            bfast = kind;
+            const bool q0 = lane < b.nb && mr_nm[(p0 + lane) & (META_POS - 1)] == 0;
+            const bool q1 = lane + 64 < b.nb && mr_nm[(p0 + lane + 64) & (META_POS - 1)] == 0;
+            dm0 = __ballot(q0); dm1 = __ballot(q1);
+            // slots needed by the first n markers: 2 n + 2 + 2 (dirty among them); monotone in n
+            const bool f0 = lane < b.nb && 2 * (lane + 1) + 2 + 2 * dirty_rank(dm0, dm1, lane + 1) <= SW_VMAX;
+            const bool f1 = lane + 64 < b.nb && 2 * (lane + 65) + 2 + 2 * (lane + 65 <= 127 ? dirty_rank(dm0, dm1, lane + 65) : __popcll(dm0) + __popcll(dm1)) <= SW_VMAX;
+            const int fit = __popcll(__ballot(f0)) + __popcll(__ballot(f1));
+            if (fit < b.nb) b.nb = fit;               // fit >= 1
         }
-        b.fast = bfast;
         // A marker whose effect is non-zero always changes it (bayes.cpp:479-483: the new draw differs), so
         // the walk is known to stop there: end the batch at the first such marker instead of computing dots
         // behind it that are certain to go stale.  (Every wavefront scans the same LDS words: uniform.)
@@ -1002,6 +1014,12 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             b.planned = first < b.nb;                 // the last marker of the batch has a non-zero effect
         }
         const int nb = b.nb;
+        if (!FAST) {                                  // keep the flags of the batch's positions only
+            dm0 = nb >= 64 ? dm0 : (dm0 & ((1ull << nb) - 1ull));
+            dm1 = nb >= 128 ? dm1 : (nb > 64 ? (dm1 & ((1ull << (nb - 64)) - 1ull)) : 0ull);
+        }
+        b.dm0 = dm0; b.dm1 = dm1;
+        const int nd = __popcll(dm0) + __popcll(dm1);
         li0 = LaneIn{0, 0, 0.0, 0.0, 1.0};
         li1 = LaneIn{0, 0, 0.0, 0.0, 1.0};
         if (wave == 0 && lane < nb) {
@@ -1098,12 +1116,14 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                         if ((n & 3) == 0 && n < 8 && m < nb) atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)sx);
                     } else {
                         // a = c' - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
-                        // slice's sum of d is added at the publish
+                        // slice's sum of d is added at the publish.  (A clean marker in this tile has Z = 0: code 11
+                        // occurs for it only where the residual is 0.)
                         const int z = zcc0[q][r] + (zcc1[q][r] >> 2) + (zcc2[q][r] >> 4);
                         const long long sz = quad_sum64((long long)z << (8 * (n & 3)));
                         if ((n & 3) == 0 && n < 8 && m < nb) {
-                            atomicAdd(&s_sum[4 * m + (n >> 2)], (unsigned long long)(sx - 3 * sz));
-                            atomicAdd(&s_sum[4 * m + 2 + (n >> 2)], (unsigned long long)(-sz));
+                            atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)(sx - 3 * sz));
+                            if (dirty_at(dm0, dm1, m))
+                                atomicAdd(&s_sum[2 * nb + 2 + 2 * dirty_rank(dm0, dm1, m) + (n >> 2)], (unsigned long long)(-sz));
                         }
                     }
                 }
@@ -1111,36 +1131,37 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         };
         using IC1 = std::integral_constant<int, 1>;
         using IC2 = std::integral_constant<int, 2>;
-        auto tiles = [&](auto fast_tag) {
-            if (ksplit == 1) {                        // four or more tiles: every wavefront walks whole slices, two tiles at a time
-#pragma unroll 1
-                for (int t = wt; t < nt; t += 8) {
-                    if (t + 4 < nt) tile_pass(std::integral_constant<int, SS>{}, IC2{}, fast_tag, t);    // tiles t and t + 4 share operand B
-                    else tile_pass(std::integral_constant<int, SS>{}, IC1{}, fast_tag, t);
-                }
-            } else {                                  // fewer tiles than wavefronts: the slice is split ksplit ways
-#pragma unroll 1
-                for (int t = wt; t < nt; t += tsplit) {
-                    if (ksplit == 2) tile_pass(std::integral_constant<int, SS / 2>{}, IC1{}, fast_tag, t);
-                    else tile_pass(std::integral_constant<int, SS / 4>{}, IC1{}, fast_tag, t);
-                }
-            }
+        // the 16 positions of tile t hold a dirty marker?  (tiles 0..3: dm0, 4..7: dm1)
+        auto tile_dirty = [&](int t) { return (((t < 4 ? dm0 >> (16 * t) : dm1 >> (16 * (t - 4))) & 0xffffull) != 0ull); };
+        auto one_pass = [&](auto ns_tag, auto nt_tag, int t, bool dirty) {
+            if constexpr (FAST) tile_pass(ns_tag, nt_tag, std::true_type{}, t);
+            else { if (dirty) tile_pass(ns_tag, nt_tag, std::false_type{}, t); else tile_pass(ns_tag, nt_tag, std::true_type{}, t); }
         };
-        if constexpr (FAST) tiles(std::true_type{});
-        else { if (bfast) tiles(std::true_type{}); else tiles(std::false_type{}); }
+        if (ksplit == 1) {                            // four or more tiles: every wavefront walks whole slices, two tiles at a time
+#pragma unroll 1
+            for (int t = wt; t < nt; t += 8) {
+                if (t + 4 < nt) one_pass(std::integral_constant<int, SS>{}, IC2{}, t, tile_dirty(t) || tile_dirty(t + 4));   // tiles t and t + 4 share operand B
+                else one_pass(std::integral_constant<int, SS>{}, IC1{}, t, tile_dirty(t));
+            }
+        } else {                                      // fewer tiles than wavefronts: the slice is split ksplit ways
+#pragma unroll 1
+            for (int t = wt; t < nt; t += tsplit) {
+                if (ksplit == 2) one_pass(std::integral_constant<int, SS / 2>{}, IC1{}, t, tile_dirty(t));
+                else one_pass(std::integral_constant<int, SS / 4>{}, IC1{}, t, tile_dirty(t));
+            }
+        }
         PA(2);
         lds_barrier();                                // the LDS sums are complete (prefetches stay in flight)
         PA(3);
-        const bool fast = bfast;
-        const int nv = fast ? 2 * nb + 2 : 4 * nb;
+        const int nv = 2 * nb + 2 + 2 * nd;
         if (tid < nv) {
             double tot;
-            if (fast && tid >= 2 * nb) {
+            if (tid >= 2 * nb && tid < 2 * nb + 2) {  // sum q1, sum q2 over the slice
                 const int w2 = tid - 2 * nb;
                 tot = s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2];
             } else {
                 long long v = (long long)s_sum[tid];
-                if (!fast && (tid & 2)) {             // sum b d = sum d - Z: this slice's sum of the exact part, as an integer
+                if (tid >= 2 * nb + 2) {              // dirty marker: sum b d = sum d - Z, this slice's sum of the exact part as an integer
                     const int w2 = tid & 1;
                     const double dsum = s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2];
                     v += (long long)(dsum * (w2 ? 0x1p53 : 0x1p22));                // exact: a multiple of the grid, < 2^53 units
@@ -1182,7 +1203,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         return bad;
     };
 
-    Batch cur{0, 0, 0, 0u, false, FAST}, nxt{0, 0, 0, 0u, false, FAST}, tb{0, 0, 0, 0u, false, FAST};
+    Batch cur{0, 0, 0, 0u, false, 0ull, 0ull}, nxt{0, 0, 0, 0u, false, 0ull, 0ull}, tb{0, 0, 0, 0u, false, 0ull, 0ull};
     LaneIn li_cur0{0, 0, 0.0, 0.0, 1.0}, li_cur1{0, 0, 0.0, 0.0, 1.0}, li_nxt0{0, 0, 0.0, 0.0, 1.0}, li_nxt1{0, 0, 0.0, 0.0, 1.0};
     bool bad = false;
     {
@@ -1248,7 +1269,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
             Totals tot0{0.0, 0.0, 0.0, 0.0}, tot1{0.0, 0.0, 0.0, 0.0};
-            const bool okw = poll_totals(cur.nb, cur.fast, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word, spin_limit);
+            const bool okw = poll_totals(cur.nb, cur.nv, cur.dm0, cur.dm1, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word, spin_limit);
             if (lane == 0) *reinterpret_cast<volatile int*>(&ctl[C_TOTF]) = (int)(cur.gen + 1u);   // the loaders may start
             TRACE(3);
             PROF(4);   // wait for the totals
@@ -1294,7 +1315,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         const int n_done = ctl[C_NDONE];
         const bool upd = ctl[C_UPD] != 0;
         n_planned += ctl[C_PLN];
-        n_fastb += cur.fast ? 1 : 0;
+        n_fastb += (cur.dm0 | cur.dm1) == 0ull ? 1 : 0;
         n_stale += cur.nb - n_done;                   // dots computed behind the stop: thrown away
         if (upd) {
             n_upd++;

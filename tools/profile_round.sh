@@ -13,7 +13,7 @@ echo "== bench c3 (default: 2 warm-up + 5 timed sweeps, CPU baseline, signal-bea
 timeout -k 10 400 $B > $OUT/bench_c3.json 2> $OUT/bench_c3.err || exit 1
 echo "== bench c3 as the driver runs it (--steps 20 --warmup 5)"
 timeout -k 10 400 $B --steps 20 --warmup 5 --no-cpu-baseline --no-signal > $OUT/bench_c3_20steps.json 2>> $OUT/bench_c3.err || exit 1
-for wl in c2 c4 c5; do
+for wl in c2 c4 c5 c6; do
   echo "== bench $wl"
   timeout -k 10 400 $B --workload $wl --no-cpu-baseline --no-signal > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err || exit 1
 done
