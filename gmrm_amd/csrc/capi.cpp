@@ -337,8 +337,9 @@ int gmrm_marker_stats(gmrm_ctx* c, int t) {
     {   // one flag per block: can the sweep use the 2-value exchange layout?
         std::vector<uint8_t> nm((size_t)c->M);
         if (c->M > 0) HIPCHK(hipMemcpy(nm.data(), tr.nomiss, (size_t)c->M, hipMemcpyDeviceToHost));
-        tr.all_nomiss = 1;
-        for (uint8_t v : nm) if (!v) { tr.all_nomiss = 0; break; }
+        size_t clean = 0;
+        for (uint8_t v : nm) clean += v ? 1 : 0;
+        tr.miss_mode = clean == nm.size() ? 0 : (clean == 0 ? 2 : 1);
     }
     tr.have_stats = true;
     return GMRM_OK;
@@ -361,7 +362,7 @@ int gmrm_set_marker_stats(gmrm_ctx* c, int t, const double* mave, const double* 
     HIPCHK(hipMemcpy(c->tr[t].msig, msig, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(c->tr[t].nomiss, 0, (size_t)(c->M > 0 ? c->M : 1)));   // unknown: general exchange layout
     HIPCHK(hipDeviceSynchronize());
-    c->tr[t].all_nomiss = 0;
+    c->tr[t].miss_mode = 2;
     c->tr[t].have_stats = true;
     return GMRM_OK;
 }
@@ -582,8 +583,8 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     }
     a.nb_factor16 = c->nb_factor16;
     a.spec_factor16 = c->spec_factor16;
-    a.all_nomiss = tr.all_nomiss;
-    if (std::getenv("GMRM_FORCE_MIXED")) a.all_nomiss = 0;    // diagnostic: run a clean block through the per-marker-layout kernel
+    a.miss_mode = tr.miss_mode;
+    if (std::getenv("GMRM_FORCE_MIXED")) a.miss_mode = 1;     // diagnostic: run any block through the per-marker-layout kernel
     a.spin_ticks = (unsigned long long)c->spin_timeout_ms * 100000ull;      // s_memrealtime ticks (100 MHz)
     // Phenotypes that do not fit side by side share stream 0 and run one after another.
     hipStream_t st = c->tr[t % c->conc].stream;       // conc chains side by side, the others queue behind them

@@ -24,7 +24,7 @@ struct Trait {
     int nonas = 0;
     bool have_trait = false, have_stats = false, in_flight = false, empty = false;
     bool poisoned = false;          // a sweep failed inside the kernel: comp / acum partly written, sweeps refused until re-upload
-    int all_nomiss = 0;             // every marker of the block: nomiss == 1
+    int miss_mode = 2;              // markers of the block with nomiss == 0: 0 none, 1 some, 2 all (or unknown)
     int G = 0, K = 0;
     // sweep workspace
     int* order = nullptr;

@@ -553,16 +553,23 @@ __device__ __forceinline__ bool poll_totals(int nb, int nv, unsigned long long d
         s_tot[64 * k + lane] = __longlong_as_double((long long)(((unsigned long long)d[k].z << 32) | d[k].x));
     Totals t0{0.0, 0.0, 0.0, 0.0}, t1{0.0, 0.0, 0.0, 0.0};
     const double sq1 = s_tot[2 * nb], sq2 = s_tot[2 * nb + 1];
-    if (lane < nb) {
-        const int zs = dirty_at(dm0, dm1, lane) ? 2 * nb + 2 + 2 * dirty_rank(dm0, dm1, lane) : 2 * nb;
-        t0 = Totals{s_tot[2 * lane], s_tot[2 * lane + 1], s_tot[zs], s_tot[zs + 1]};
+    if ((dm0 | dm1) == 0ull) {                   // (uniform) the usual case: no dirty marker in the batch
+        if (lane < nb) t0 = Totals{s_tot[2 * lane], s_tot[2 * lane + 1], sq1, sq2};
+        if (lane + 64 < nb) t1 = Totals{s_tot[2 * lane + 128], s_tot[2 * lane + 129], sq1, sq2};
+    } else if (__popcll(dm0) + __popcll(dm1) == nb) {   // (uniform) every marker dirty: the r-th dirty marker is position r
+        if (lane < nb) t0 = Totals{s_tot[2 * lane], s_tot[2 * lane + 1], s_tot[2 * nb + 2 + 2 * lane], s_tot[2 * nb + 3 + 2 * lane]};
+        if (lane + 64 < nb) t1 = Totals{s_tot[2 * lane + 128], s_tot[2 * lane + 129], s_tot[2 * nb + 130 + 2 * lane], s_tot[2 * nb + 131 + 2 * lane]};
+    } else {
+        if (lane < nb) {
+            const int zs = dirty_at(dm0, dm1, lane) ? 2 * nb + 2 + 2 * dirty_rank(dm0, dm1, lane) : 2 * nb;
+            t0 = Totals{s_tot[2 * lane], s_tot[2 * lane + 1], s_tot[zs], s_tot[zs + 1]};
+        }
+        if (lane + 64 < nb) {
+            const int p = lane + 64;
+            const int zs = dirty_at(dm0, dm1, p) ? 2 * nb + 2 + 2 * dirty_rank(dm0, dm1, p) : 2 * nb;
+            t1 = Totals{s_tot[2 * p], s_tot[2 * p + 1], s_tot[zs], s_tot[zs + 1]};
+        }
     }
-    if (lane + 64 < nb) {
-        const int p = lane + 64;
-        const int zs = dirty_at(dm0, dm1, p) ? 2 * nb + 2 + 2 * dirty_rank(dm0, dm1, p) : 2 * nb;
-        t1 = Totals{s_tot[2 * p], s_tot[2 * p + 1], s_tot[zs], s_tot[zs + 1]};
-    }
-    (void)sq1; (void)sq2;
     tot0 = t0; tot1 = t1;
     return !__any(bad);
 }
@@ -676,8 +683,11 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
-template <int R, bool FAST>
+// MODE: which markers of the block have a missing genotype among the phenotyped individuals ("dirty"; host: the
+// flags of the marker statistics) -- 0: none, 1: some (per-marker flags decide), 2: all.
+template <int R, int MODE>
 __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
+    constexpr bool FAST = MODE == 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GE = Geo<R>;
     constexpr int NI = 4 * R;                        // individuals per thread
@@ -933,7 +943,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     pm_beta[h] = a.betas_in[pm_m[h]];
                     pm_mave[h] = a.mave[pm_m[h]];
                     pm_msig[h] = a.msig[pm_m[h]];
-                    if (!FAST) pm_nm[h] = a.nomiss[pm_m[h]];
+                    if (MODE == 1) pm_nm[h] = a.nomiss[pm_m[h]];
                 }
             }
         }
@@ -948,7 +958,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 if (64 * h + lane < nc) {
                     const int sl = (mhi + 64 * h + lane) & (META_POS - 1);
                     mr_m[sl] = pm_m[h]; mr_g[sl] = pm_g[h]; mr_beta[sl] = pm_beta[h]; mr_mave[sl] = pm_mave[h]; mr_msig[sl] = pm_msig[h];
-                    if (!FAST) mr_nm[sl] = (uint8_t)pm_nm[h];
+                    if (MODE == 1) mr_nm[sl] = (uint8_t)pm_nm[h];
                 }
             }
         }
@@ -992,15 +1002,24 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // Dirty markers (a missing genotype among the phenotyped individuals) exchange two more values each: the batch
         // is cut where the slots run out.  (Every wavefront reads the same LDS bytes: uniform.)
         unsigned long long dm0 = 0ull, dm1 = 0ull;
-        if (!FAST) {
+        if (MODE == 2) {                              // every marker dirty: 4 slots each, the r-th dirty marker is position r
+            if (b.nb > (SW_VMAX - 2) / 4) b.nb = (SW_VMAX - 2) / 4;
+            dm0 = ~0ull; dm1 = ~0ull;
+        }
+        if (MODE == 1) {
             const bool q0 = lane < b.nb && mr_nm[(p0 + lane) & (META_POS - 1)] == 0;
             const bool q1 = lane + 64 < b.nb && mr_nm[(p0 + lane + 64) & (META_POS - 1)] == 0;
             dm0 = __ballot(q0); dm1 = __ballot(q1);
-            // slots needed by the first n markers: 2 n + 2 + 2 (dirty among them); monotone in n
-            const bool f0 = lane < b.nb && 2 * (lane + 1) + 2 + 2 * dirty_rank(dm0, dm1, lane + 1) <= SW_VMAX;
-            const bool f1 = lane + 64 < b.nb && 2 * (lane + 65) + 2 + 2 * (lane + 65 <= 127 ? dirty_rank(dm0, dm1, lane + 65) : __popcll(dm0) + __popcll(dm1)) <= SW_VMAX;
-            const int fit = __popcll(__ballot(f0)) + __popcll(__ballot(f1));
-            if (fit < b.nb) b.nb = fit;               // fit >= 1
+            const int ndall = __popcll(dm0) + __popcll(dm1);
+            if (ndall == b.nb) {                      // (uniform) every marker dirty: 4 slots each
+                if (b.nb > (SW_VMAX - 2) / 4) b.nb = (SW_VMAX - 2) / 4;
+            } else if (2 * b.nb + 2 + 2 * ndall > SW_VMAX) {   // (uniform) the slots run out inside the batch: find where
+                // slots needed by the first n markers: 2 n + 2 + 2 (dirty among them); monotone in n
+                const bool f0 = lane < b.nb && 2 * (lane + 1) + 2 + 2 * dirty_rank(dm0, dm1, lane + 1) <= SW_VMAX;
+                const bool f1 = lane + 64 < b.nb && 2 * (lane + 65) + 2 + 2 * (lane + 65 <= 127 ? dirty_rank(dm0, dm1, lane + 65) : ndall) <= SW_VMAX;
+                const int fit = __popcll(__ballot(f0)) + __popcll(__ballot(f1));
+                if (fit < b.nb) b.nb = fit;           // fit >= 1
+            }
         }
         // A marker whose effect is non-zero always changes it (bayes.cpp:479-483: the new draw differs), so
         // the walk is known to stop there: end the batch at the first such marker instead of computing dots
@@ -1020,6 +1039,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
         b.dm0 = dm0; b.dm1 = dm1;
         const int nd = __popcll(dm0) + __popcll(dm1);
+        const bool all_dirty = MODE == 2 || nd == nb; // then the r-th dirty marker is batch position r
         li0 = LaneIn{0, 0, 0.0, 0.0, 1.0};
         li1 = LaneIn{0, 0, 0.0, 0.0, 1.0};
         if (wave == 0 && lane < nb) {
@@ -1122,8 +1142,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                         const long long sz = quad_sum64((long long)z << (8 * (n & 3)));
                         if ((n & 3) == 0 && n < 8 && m < nb) {
                             atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)(sx - 3 * sz));
-                            if (dirty_at(dm0, dm1, m))
-                                atomicAdd(&s_sum[2 * nb + 2 + 2 * dirty_rank(dm0, dm1, m) + (n >> 2)], (unsigned long long)(-sz));
+                            if (all_dirty || dirty_at(dm0, dm1, m))
+                                atomicAdd(&s_sum[2 * nb + 2 + 2 * (all_dirty ? m : dirty_rank(dm0, dm1, m)) + (n >> 2)], (unsigned long long)(-sz));
                         }
                     }
                 }
@@ -1134,7 +1154,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // the 16 positions of tile t hold a dirty marker?  (tiles 0..3: dm0, 4..7: dm1)
         auto tile_dirty = [&](int t) { return (((t < 4 ? dm0 >> (16 * t) : dm1 >> (16 * (t - 4))) & 0xffffull) != 0ull); };
         auto one_pass = [&](auto ns_tag, auto nt_tag, int t, bool dirty) {
-            if constexpr (FAST) tile_pass(ns_tag, nt_tag, std::true_type{}, t);
+            if constexpr (MODE == 0) tile_pass(ns_tag, nt_tag, std::true_type{}, t);
+            else if constexpr (MODE == 2) tile_pass(ns_tag, nt_tag, std::false_type{}, t);
             else { if (dirty) tile_pass(ns_tag, nt_tag, std::false_type{}, t); else tile_pass(ns_tag, nt_tag, std::true_type{}, t); }
         };
         if (ksplit == 1) {                            // four or more tiles: every wavefront walks whole slices, two tiles at a time
@@ -1393,15 +1414,19 @@ int sweep_pick_R(size_t stride, int max_wg, int* W_out) {
     return -1;
 }
 
-template <int R, bool FAST> static hipError_t launch_RF(const SweepArgs& a, hipStream_t st, int grid) {
+template <int R, int MODE> static hipError_t launch_RF(const SweepArgs& a, hipStream_t st, int grid) {
     const int lds = lds_total<R>();
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_sweep<R, FAST>), dim3(grid), dim3(SW_TPB), lds, st, a);
+    hipLaunchKernelGGL((k_sweep<R, MODE>), dim3(grid), dim3(SW_TPB), lds, st, a);
     return hipGetLastError();
 }
 template <int R> static hipError_t launch_R(const SweepArgs& a, hipStream_t st, int grid) {
-    return a.all_nomiss ? launch_RF<R, true>(a, st, grid) : launch_RF<R, false>(a, st, grid);
+    switch (a.miss_mode) {
+        case 0: return launch_RF<R, 0>(a, st, grid);
+        case 2: return launch_RF<R, 2>(a, st, grid);
+        default: return launch_RF<R, 1>(a, st, grid);
+    }
 }
 
 // `grid` is a.W except in the fault-injection test (one workgroup short: the grid-wide wait must time out).
@@ -1421,13 +1446,13 @@ hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) {
 template <int R> static hipError_t occupancy_R(int* out) {
     const int lds = lds_total<R>();
     int n0 = 0, n1 = 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_sweep<R, true>, SW_TPB, (size_t)lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_sweep<R, 0>, SW_TPB, (size_t)lds);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_sweep<R, false>, SW_TPB, (size_t)lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_sweep<R, 1>, SW_TPB, (size_t)lds);
     if (e != hipSuccess) return e;
     *out = n0 < n1 ? n0 : n1;
     return hipSuccess;

@@ -127,3 +127,33 @@ def test_c4_four_traits_at_full_width_run_as_queued_pairs(gpu):
     assert len({c.betas.tobytes() for c in chains}) == T   # four different chains
     smp.close()
     ctx.close()
+
+
+def test_largest_supported_width_one_workgroup_per_compute_unit(gpu):
+    """The widest geometry: N = 256 workgroups x 256 threads x 4 bytes x 4 individuals = 1 048 576 (R = 4, one
+    workgroup on every compute unit), and one more individual is refused with the limit in the message."""
+    ncu = gmrm_amd.Context(64, 1).geometry()["num_cu"]
+    N = min(ncu, 256) * 256 * 4 * 4
+    M = 96
+    rng = np.random.default_rng(12)
+    ctx = gmrm_amd.Context(N, M)
+    g = ctx.geometry()
+    assert (g["R"], g["W"]) == (4, min(ncu, 256))
+    ctx.synth_bed(3, 0.4, 0.0)
+    bed = ctx.download_bed()
+    eps, mask4, nonas = orc.phen_prepare(rng.normal(size=N), (rng.random(N) < 0.01).astype(np.uint8))
+    ctx.upload_trait(0, eps, mask4, nonas)
+    cva = np.array([[0.0, 0.0001, 0.001, 0.01]])
+    gi = np.zeros(M, dtype=np.int32)
+    smp = gmrm_amd.Sampler(ctx, 5, cva, gi)
+    ch = orc.Chain(N, bed, eps, mask4, nonas, gi, cva, 5, canon=True)
+    for it in (1, 2):
+        smp.iterate(it)
+        ch.iterate(it)
+        assert np.array_equal(ctx.comp(0), ch.comp) and np.array_equal(ctx.betas(0), ch.betas)
+    assert np.array_equal(ctx.get_epsilon(0), ch.eps)
+    smp.close()
+    ctx.close()
+    with pytest.raises(gmrm_amd._lib.GmrmError) as ei:
+        gmrm_amd.Context(N + 1, M)
+    assert "N too large" in str(ei.value) and str(N) in str(ei.value)
