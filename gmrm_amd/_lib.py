@@ -71,6 +71,7 @@ SIGNATURES = {
     "gmrm_group_create": (C.c_int, [C.POINTER(VP), C.c_int, C.POINTER(VP), C.POINTER(VP), C.c_int, C.c_int, C.c_int]),
     "gmrm_group_uses_rccl": (C.c_int, [VP]),
     "gmrm_group_iterate": (C.c_int, [VP, C.c_int]),
+    "gmrm_group_iterate_steps": (C.c_int, [VP, C.c_int]),
     "gmrm_group_destroy": (C.c_int, [VP]),
     "gmrm_rccl_selftest": (C.c_int, [C.c_int]),
     "gmrm_predict_g": (C.c_int, [VP, C.c_int, c_double_p, c_double_p]),
@@ -85,6 +86,7 @@ SIGNATURES = {
     "gmrm_set_marker_stats": (C.c_int, [VP, C.c_int, c_double_p, c_double_p]),
     "gmrm_dot": (C.c_int, [VP, C.c_int, C.c_int, C.c_double, C.c_double, c_double_p]),
     "gmrm_update_eps": (C.c_int, [VP, C.c_int, C.c_int, c_double_p]),
+    "gmrm_update_eps_from": (C.c_int, [VP, C.c_int, VP, C.c_int, c_double_p]),
     "gmrm_offset_eps": (C.c_int, [VP, C.c_int, C.c_double]),
     "gmrm_sumsqr": (C.c_int, [VP, C.c_int, c_double_p]),
     "gmrm_eps_sigma": (C.c_int, [VP, C.c_int, c_double_p]),
@@ -96,6 +98,7 @@ SIGNATURES = {
     "gmrm_get_acum": (C.c_int, [VP, C.c_int, c_double_p]),
     "gmrm_set_betas": (C.c_int, [VP, C.c_int, c_double_p]),
     "gmrm_set_comp": (C.c_int, [VP, C.c_int, c_int_p]),
+    "gmrm_set_acum": (C.c_int, [VP, C.c_int, c_double_p]),
     "gmrm_sampler_save": (C.c_int, [VP, C.c_char_p, C.c_int]),
     "gmrm_sampler_load": (C.c_int, [VP, C.c_char_p, c_int_p]),
     "gmrm_selftest_math": (C.c_int, [C.c_int, C.c_int, c_double_p, c_double_p, C.c_int]),
@@ -110,6 +113,9 @@ SIGNATURES = {
     "gmrm_sampler_begin_sweep": (C.c_int, [VP, c_double_p]),
     "gmrm_sampler_end_sweep": (C.c_int, [VP, c_int_p, c_double_p]),
     "gmrm_sampler_epilogue": (C.c_int, [VP, c_int_p, c_double_p]),
+    "gmrm_sampler_begin_steps": (C.c_int, [VP, c_double_p]),
+    "gmrm_sampler_step": (C.c_int, [VP, C.c_int, c_int_p, c_double_p]),
+    "gmrm_sampler_end_steps": (C.c_int, [VP, c_int_p, c_double_p]),
     "gmrm_sampler_adopt": (C.c_int, [VP, C.c_int, c_double_p, c_double_p, C.c_double]),
     "gmrm_sampler_get": (C.c_int, [VP, C.c_int, C.POINTER(HyperC)]),
     "gmrm_sampler_csv_line": (C.c_int, [VP, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),

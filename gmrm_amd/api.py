@@ -185,6 +185,11 @@ class Context:
         d = np.ascontiguousarray(dbeta3, dtype=np.float64)
         check(self.lib.gmrm_update_eps(self.h, int(t), int(mloc), _dp(d)))
 
+    def update_epsilon_from(self, src, dbeta3, mloc, t=0):
+        """Bayes::update_epsilon for one sender (src/bayes.cpp:681-706): marker `mloc` of context `src`."""
+        d = np.ascontiguousarray(dbeta3, dtype=np.float64)
+        check(self.lib.gmrm_update_eps_from(self.h, int(t), src.h, int(mloc), _dp(d)))
+
     def offset_epsilon(self, offset, t=0):
         """Phenotype::offset_epsilon (src/phenotype.cpp:395-411)."""
         check(self.lib.gmrm_offset_eps(self.h, int(t), float(offset)))
@@ -315,6 +320,25 @@ class Sampler:
         cass = np.zeros((T, self.G, self.K), dtype=np.int32)
         bsq = np.zeros((T, self.G), dtype=np.float64)
         check(self.lib.gmrm_sampler_end_sweep(self.h, _ip(cass), _dp(bsq)))
+        return cass, bsq
+
+    # the reference's per-step schedule (src/bayes.cpp:374-553 with several MPI tasks; see include/gmrm_hip.h)
+    def begin_steps(self, mu):
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        check(self.lib.gmrm_sampler_begin_steps(self.h, _dp(mu)))
+
+    def step(self, mrki):
+        """-> (mloc, dbeta3[T, 3]); rows are zero where the effect did not change."""
+        mloc = C.c_int(0)
+        d3 = np.zeros((self.ctx.T, 3), dtype=np.float64)
+        check(self.lib.gmrm_sampler_step(self.h, int(mrki), C.byref(mloc), _dp(d3)))
+        return mloc.value, d3
+
+    def end_steps(self):
+        T = self.ctx.T
+        cass = np.zeros((T, self.G, self.K), dtype=np.int32)
+        bsq = np.zeros((T, self.G), dtype=np.float64)
+        check(self.lib.gmrm_sampler_end_steps(self.h, _ip(cass), _dp(bsq)))
         return cass, bsq
 
     def epilogue(self, cass, beta_sqn):

@@ -209,7 +209,7 @@ int gmrm_ctx_destroy(gmrm_ctx* c) {
         if (tr.ev1) hipEventDestroy(tr.ev1);
         if (tr.stream) hipStreamDestroy(tr.stream);
     }
-    hipFree(c->bed); hipFree(c->group);
+    hipFree(c->bed); hipFree(c->group); hipFree(c->colbuf);
     delete c;
     return GMRM_OK;
 }
@@ -395,6 +395,35 @@ int gmrm_update_eps(gmrm_ctx* c, int t, int mloc, const double* dbeta) {
     const double v2 = (mdb * 1.0 + 1.0) * bs_;
     const double v3 = (mdb * 1.0 + 0.0) * bs_;
     HIPCHK(launch_update(tr.eps, c->bed + (size_t)mloc * c->stride, tr.namask2, c->stride, v0, v1, v2, v3, tr.stream));
+    HIPCHK(hipStreamSynchronize(tr.stream));
+    return GMRM_OK;
+}
+
+// bayes.cpp:681-706 as one MPI task sees it: the changed marker of ANOTHER task (its column arrived through
+// MPI_Allgatherv, bayes.cpp:537-541) applied to this task's residual replica.  `src` holds the column (marker
+// mloc of its block); with src == c this is gmrm_update_eps.  The column is copied device to device into a
+// staging buffer of c when the two contexts sit on different devices.
+int gmrm_update_eps_from(gmrm_ctx* c, int t, gmrm_ctx* src, int mloc, const double* dbeta) {
+    if (int r = need_trait(c, t, true)) return r;
+    if (!src || !dbeta) return fail(GMRM_EINVAL, "null argument");
+    if (src == c) return gmrm_update_eps(c, t, mloc, dbeta);
+    if (!src->have_bed || mloc < 0 || mloc >= src->M) return fail(GMRM_EINVAL, "marker index out of range");
+    if (src->N != c->N || src->stride != c->stride) return fail(GMRM_EINVAL, "the two contexts hold different individuals");
+    HIPCHK(hipSetDevice(c->device));
+    Trait& tr = c->tr[t];
+    const uint8_t* col = src->bed + (size_t)mloc * src->stride;
+    if (src->device != c->device) {
+        if (!c->colbuf) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->colbuf), c->stride));
+        HIPCHK(hipMemcpyPeerAsync(c->colbuf, c->device, col, src->device, c->stride, tr.stream));
+        col = c->colbuf;
+    }
+    const double bs_ = dbeta[0] * dbeta[2];                    // phenotype.cpp:328-329
+    const double mdb = -dbeta[1];
+    const double v0 = (mdb * 1.0 + 2.0) * bs_;                 // phenotype.cpp:385-388 per 2-bit code
+    const double v1 = (mdb * 0.0 + 0.0) * bs_;
+    const double v2 = (mdb * 1.0 + 1.0) * bs_;
+    const double v3 = (mdb * 1.0 + 0.0) * bs_;
+    HIPCHK(launch_update(tr.eps, col, tr.namask2, c->stride, v0, v1, v2, v3, tr.stream));
     HIPCHK(hipStreamSynchronize(tr.stream));
     return GMRM_OK;
 }
@@ -710,6 +739,13 @@ int gmrm_set_comp(gmrm_ctx* c, int t, const int* comp) {
     if (!comp) return fail(GMRM_EINVAL, "null argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(c->tr[t].comp, comp, (size_t)c->M * sizeof(int), hipMemcpyHostToDevice));
+    return GMRM_OK;
+}
+int gmrm_set_acum(gmrm_ctx* c, int t, const double* acum) {
+    if (int r = ctx_check_t(c, t)) return r;
+    if (!acum) return fail(GMRM_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->tr[t].acum, acum, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice));
     return GMRM_OK;
 }
 int gmrm_get_acum(gmrm_ctx* c, int t, double* acum) {

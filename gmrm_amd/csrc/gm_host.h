@@ -54,6 +54,7 @@ struct gmrm_ctx {
     size_t mbytes = 0, stride = 0;
     uint8_t* bed = nullptr;         // Bayes::bed_data, column stride padded to 16 bytes
     int* group = nullptr;           // Bayes::group_index[S .. S+M)
+    uint8_t* colbuf = nullptr;      // one column of another shard (per-step schedule, gmrm_update_eps_from)
     std::vector<gm::Trait> tr;
     int num_cu = 0, R = 0, W = 0, Wpad = 0, conc = 1;   // conc: chains that sweep side by side
     int max_resident_wg = 0;        // occupancy query x num_cu for the sweep kernel at this R

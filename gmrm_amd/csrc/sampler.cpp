@@ -29,6 +29,10 @@ struct Chain {                       // class Phenotype, the host-resident part
     long long n_updates = 0, n_batches = 0, n_planned = 0, n_stale = 0, n_fastb = 0;
     double sweep_ms = 0.0;
     bool preshuffled = false;        // midx already holds the NEXT iteration's order (shuffled while the GPU swept)
+    // host copies the per-step schedule works on (gmrm_sampler_begin_steps .. _end_steps)
+    std::vector<int> comp;
+    std::vector<double> acum, mave, msig;
+    bool stepping = false;
 };
 
 const char CKP_MAGIC[8] = {'G', 'M', 'R', 'M', 'C', 'K', 'P', '1'};                // checkpoint files (gmrm_sampler_save / _load)
@@ -169,6 +173,139 @@ int gmrm_sampler_begin_sweep(gmrm_sampler* s, const double* mu_use) {
             gm::shuffle(c.dist_m, c.midx.data(), ctx->M);
             c.preshuffled = true;
         }
+    return GMRM_OK;
+}
+
+// ---- the reference's per-step schedule (bayes.cpp:374-553 as several MPI tasks run it) -----------------------
+// One marker step is one gmrm_dot (device), the Gibbs draw of bayes.cpp:396-492 on the host with the same
+// arithmetic as the sweep kernel (gm::exp_, the draws of gm_rng.h), and -- by the caller, for the changed markers
+// of ALL shards in shard order -- gmrm_update_eps_from on every residual replica (bayes.cpp:681-706).  A launch
+// and a device-to-host copy per marker: the reference's own communication pattern, kept as the schedule whose
+// chain is `mpiexec -n R gmrm`'s, not as a fast path (the sweep kernel is that).
+
+// bayes.cpp:358-367 with this shard's mu; no launch
+int gmrm_sampler_begin_steps(gmrm_sampler* s, const double* mu_use) {
+    if (!s || !mu_use) return fail(GMRM_EINVAL, "null argument");
+    gmrm_ctx* ctx = s->ctx;
+    for (int t = 0; t < ctx->T; t++) {
+        Chain& c = s->ch[t];
+        if (c.stepping) return fail(GMRM_ESTATE, "gmrm_sampler_begin_steps: the previous per-step sweep was not ended");
+        c.mu = mu_use[t];
+        if (int r = gmrm_offset_eps(ctx, t, -c.mu)) return r;
+        if (s->shuffle && !c.preshuffled) gm::shuffle(s->mimic_hydra ? c.dist_d : c.dist_m, c.midx.data(), ctx->M);
+        c.preshuffled = false;
+        std::fill(c.m0.begin(), c.m0.end(), 0);
+        std::fill(c.cass.begin(), c.cass.end(), 0);
+        c.comp.resize(ctx->M); c.acum.resize(ctx->M); c.mave.resize(ctx->M); c.msig.resize(ctx->M);
+        if (ctx->M > 0) {
+            if (int r = gmrm_get_betas(ctx, t, c.betas.data())) return r;
+            if (int r = gmrm_get_comp(ctx, t, c.comp.data())) return r;
+            if (int r = gmrm_get_acum(ctx, t, c.acum.data())) return r;
+            if (int r = gmrm_get_marker_stats(ctx, t, c.mave.data(), c.msig.data())) return r;
+        }
+        c.n_updates = 0; c.n_batches = 0; c.n_planned = 0; c.n_stale = 0; c.n_fastb = 0; c.sweep_ms = 0.0;
+        c.stepping = true;
+    }
+    return GMRM_OK;
+}
+
+// bayes.cpp:376-492 for step mrki of this shard: *mloc = phenotype 0's mrki-th marker (bayes.cpp:384) and, per
+// phenotype, dbeta3[3t..3t+2] = {dbeta, mave, msig} (all zero when the effect did not change or mrki >= M:
+// "share_mrk is false").  The residual is NOT touched: the caller applies the updates of every shard.
+int gmrm_sampler_step(gmrm_sampler* s, int mrki, int* mloc_out, double* dbeta3) {
+    if (!s || !mloc_out || !dbeta3 || mrki < 0) return fail(GMRM_EINVAL, "bad argument");
+    gmrm_ctx* ctx = s->ctx;
+    const int K = s->K;
+    for (int i = 0; i < 3 * ctx->T; i++) dbeta3[i] = 0.0;
+    *mloc_out = 0;
+    if (mrki >= ctx->M) return GMRM_OK;
+    const int mloc = s->ch[0].midx[mrki];
+    const int mgrp = s->group_index[ctx->S + mloc];
+    *mloc_out = mloc;
+    for (int t = 0; t < ctx->T; t++) {
+        Chain& c = s->ch[t];
+        if (!c.stepping) return fail(GMRM_ESTATE, "gmrm_sampler_step outside gmrm_sampler_begin_steps .. _end_steps");
+        if (c.sigmag[mgrp] == 0.0) {                                               // bayes.cpp:396-400
+            c.acum[mloc] = 1.0;
+            c.betas[mloc] = 0.0;
+            continue;
+        }
+        const double beta = c.betas[mloc];
+        const double nm1 = (double)(ctx->tr[t].nonas - 1);
+        const double sige_g = c.sigmae / c.sigmag[mgrp];
+        const double sigg_e = 1.0 / sige_g;
+        const double inv2sige = 1.0 / (2.0 * c.sigmae);
+        double denom[gm::KMAX], muk[gm::KMAX], logl[gm::KMAX];
+        muk[0] = 0.0; denom[0] = 0.0;
+        for (int i = 1; i < K; i++) {
+            const double cvai = 1.0 / s->cva[mgrp * K + i];                        // options.cpp:282
+            denom[i] = (double)(ctx->N - 1) + sige_g * cvai;
+        }
+        double num = 0.0;
+        if (int r = gmrm_dot(ctx, t, mloc, c.mave[mloc], c.msig[mloc], &num)) return r;
+        num += beta * nm1;
+        for (int i = 1; i < K; i++) muk[i] = num / denom[i];
+        for (int i = 0; i < K; i++) {                                              // bayes.cpp:426-432
+            logl[i] = std::log(c.pi_est[mgrp * K + i]);
+            if (i > 0) logl[i] = logl[i] + (-0.5 * std::log(sigg_e * nm1 * s->cva[mgrp * K + i] + 1.0) + muk[i] * num * inv2sige);
+        }
+        const double prob = gm::unif(c.dist_d);
+        bool zero_acum = false;                                                    // bayes.cpp:437-445
+        double tmp1 = 0.0;
+        for (int i = 0; i < K; i++) {
+            if (std::fabs(logl[i] - logl[0]) > 700.0) zero_acum = true;
+            tmp1 += gm::exp_(logl[i] - logl[0]);
+        }
+        double acum = zero_acum ? 0.0 : 1.0 / tmp1;
+        double dbeta = beta;
+        for (int i = 0; i < K; i++) {                                              // bayes.cpp:450-477
+            if (prob <= acum || i == K - 1) {
+                c.betas[mloc] = i == 0 ? 0.0 : gm::norm(c.dist_d, muk[i], c.sigmae / denom[i]);
+                c.cass[mgrp * K + i] += 1;
+                c.comp[mloc] = i;
+                break;
+            }
+            bool zero_inc = false;
+            for (int j = i + 1; j < K; j++)
+                if (std::fabs(logl[j] - logl[i + 1]) > 700.0) zero_inc = true;
+            if (!zero_inc) {
+                double esum = 0.0;
+                for (int k = 0; k < K; k++) esum += gm::exp_(logl[k] - logl[i + 1]);
+                acum = acum + 1.0 / esum;
+            }
+        }
+        c.acum[mloc] = acum;
+        dbeta -= c.betas[mloc];
+        if (std::fabs(dbeta) > 0.0) {                                              // bayes.cpp:483-488
+            dbeta3[3 * t + 0] = dbeta;
+            dbeta3[3 * t + 1] = c.mave[mloc];
+            dbeta3[3 * t + 2] = c.msig[mloc];
+            c.n_updates += 1;
+        }
+    }
+    return GMRM_OK;
+}
+
+// effects, components and acum go back to the device; local cass and beta_sqn (bayes.cpp:565-568)
+int gmrm_sampler_end_steps(gmrm_sampler* s, int* cass, double* beta_sqn) {
+    if (!s) return fail(GMRM_EINVAL, "null sampler");
+    gmrm_ctx* ctx = s->ctx;
+    const int G = s->G, K = s->K;
+    for (int t = 0; t < ctx->T; t++) {
+        Chain& c = s->ch[t];
+        if (!c.stepping) return fail(GMRM_ESTATE, "gmrm_sampler_end_steps without gmrm_sampler_begin_steps");
+        c.stepping = false;
+        if (ctx->M > 0) {
+            if (int r = gmrm_set_betas(ctx, t, c.betas.data())) return r;
+            if (int r = gmrm_set_comp(ctx, t, c.comp.data())) return r;
+            if (int r = gmrm_set_acum(ctx, t, c.acum.data())) return r;
+        }
+        std::fill(c.beta_sqn.begin(), c.beta_sqn.end(), 0.0);
+        for (int i = 0; i < ctx->M; i++)
+            c.beta_sqn[s->group_index[ctx->S + i]] += c.betas[i] * c.betas[i];
+        if (cass) std::memcpy(cass + (size_t)t * G * K, c.cass.data(), sizeof(int) * (size_t)G * K);
+        if (beta_sqn) std::memcpy(beta_sqn + (size_t)t * G, c.beta_sqn.data(), sizeof(double) * (size_t)G);
+    }
     return GMRM_OK;
 }
 

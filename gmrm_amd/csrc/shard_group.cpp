@@ -200,6 +200,56 @@ extern "C" int gmrm_group_iterate(gmrm_group* g, int it) {
     return GMRM_OK;
 }
 
+// The reference's own schedule (bayes.cpp:340-651 with several MPI tasks), one marker step at a time:
+//   1. every shard draws AND uses its own mu                                       (bayes.cpp:348-358)
+//   2. step mrki = 0 .. max M - 1: every shard draws the effect of its mrki-th marker against its own residual
+//      replica (gmrm_sampler_step); then every replica applies the changed markers of all shards in shard
+//      order -- what MPI_Allgather / MPI_Allgatherv + update_epsilon do                  (bayes.cpp:495-553, 681-706)
+//   3. cass summed, beta_sqn summed in shard order; hyper-parameter draws; shard 0's adopted   (bayes.cpp:575-651)
+// The chain is that of `mpiexec -n <shards> gmrm` (per-shard seeds, bayes.cpp:796-803).  Every step costs a
+// kernel launch and a device-to-host copy per shard plus one launch per changed marker and replica: the
+// reference's communication pattern, not a fast path -- gmrm_group_iterate is the schedule built for speed.
+extern "C" int gmrm_group_iterate_steps(gmrm_group* g, int it) {
+    if (!g) return fail(GMRM_EINVAL, "null group");
+    const int n = g->n, T = g->T, G = g->G, K = g->K;
+    std::vector<double> mu(T);
+    int Mm = 0;
+    for (int r = 0; r < n; r++) {
+        if (int rc = gmrm_sampler_draw_mu(g->smp[r], it, mu.data())) return rc;
+        if (int rc = gmrm_sampler_begin_steps(g->smp[r], mu.data())) return rc;
+        if (g->ctx[r]->M > Mm) Mm = g->ctx[r]->M;
+    }
+    std::vector<double> d3((size_t)n * T * 3);
+    std::vector<int> mloc(n);
+    for (int mrki = 0; mrki < Mm; mrki++) {
+        for (int r = 0; r < n; r++)
+            if (int rc = gmrm_sampler_step(g->smp[r], mrki, &mloc[r], &d3[(size_t)r * T * 3])) return rc;
+        for (int dst = 0; dst < n; dst++)
+            for (int r = 0; r < n; r++)                                                   // shard order (bayes.cpp:688)
+                for (int t = 0; t < T; t++) {
+                    const double* d = &d3[((size_t)r * T + t) * 3];
+                    if (d[0] != 0.0)                                                      // bayes.cpp:698
+                        if (int rc = gmrm_update_eps_from(g->ctx[dst], t, g->ctx[r], mloc[r], d)) return rc;
+                }
+    }
+    std::vector<int> cass((size_t)T * G * K, 0), c1((size_t)T * G * K);
+    std::vector<double> bsq((size_t)T * G, 0.0), b1((size_t)T * G);
+    for (int r = 0; r < n; r++) {
+        if (int rc = gmrm_sampler_end_steps(g->smp[r], c1.data(), b1.data())) return rc;
+        for (size_t i = 0; i < cass.size(); i++) cass[i] += c1[i];
+        for (size_t i = 0; i < bsq.size(); i++) bsq[i] += b1[i];
+    }
+    for (int r = 0; r < n; r++)
+        if (int rc = gmrm_sampler_epilogue(g->smp[r], cass.data(), bsq.data())) return rc;
+    for (int t = 0; t < T; t++) {
+        gmrm_hyper h;
+        if (int rc = gmrm_sampler_get(g->smp[0], t, &h)) return rc;
+        for (int r = 1; r < n; r++)
+            if (int rc = gmrm_sampler_adopt(g->smp[r], t, h.sigmag, h.pi_est, h.sigmae)) return rc;
+    }
+    return GMRM_OK;
+}
+
 // One-rank exercise of the dlopen'ed RCCL entry points (signatures, enum values, stream use) on
 // `device`: all-reduce of a small f64 buffer in place.  The multi-GPU exchange itself needs several
 // devices; this is what a one-GPU box can check of it.

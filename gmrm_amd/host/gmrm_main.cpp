@@ -43,6 +43,7 @@ struct Opts {
     bool no_rccl = false;
     unsigned ckp_every = 0;       // --checkpoint-every n: write <out-dir>/gmrm.<shard>.ckp after every n-th iteration (this build only)
     bool resume = false;          // --resume: continue from those checkpoints instead of starting over (this build only)
+    unsigned sync_every = 0;      // --sync-every 1: the reference's per-step exchange (bayes.cpp:495-553); 0 = once per sweep (this build only)
 };
 
 [[noreturn]] void fatal(const std::string& m) {
@@ -137,6 +138,12 @@ Opts parse(int argc, char** argv) {
         else if (a == "--no-rccl") { o.no_rccl = true; ss << "--no-rccl 1\n"; }   // this build only: stage the exchange through the host
         else if (a == "--checkpoint-every") { last(i); positive(i, "--checkpoint-every", 1); o.ckp_every = (unsigned)atoi(argv[++i]); ss << "--checkpoint-every " << o.ckp_every << "\n"; }
         else if (a == "--resume") { o.resume = true; ss << "--resume 1\n"; }
+        else if (a == "--sync-every") {
+            last(i);
+            o.sync_every = (unsigned)atoi(argv[++i]);
+            if (o.sync_every > 1) fatal("FATAL  : --sync-every takes 1 (exchange after every marker step, as upstream) or 0 (once per sweep)");
+            ss << "--sync-every " << o.sync_every << "\n";
+        }
         else fatal("FATAL: option \"" + a + "\" unknown");
     }
     std::cout << ss.str() << std::endl;
@@ -454,7 +461,13 @@ int main(int argc, char** argv) {
     }
     gmrm_sampler* smp = smps[0];
     gmrm_group* grp = nullptr;
-    if (nsh > 1) {                                                           // replaces the MPI calls of Bayes::process
+    if (opt.sync_every == 1) {                                               // bayes.cpp:374-553 as upstream runs it
+        need(gmrm_group_create(&grp, nsh, ctxs.data(), smps.data(), G, K, 0), "gmrm_group_create");
+        printf("INFO   : %d marker shard%s on the reference's per-step schedule: every changed marker is applied to every residual\n"
+               "       : replica before the next step (bayes.cpp:495-553, 681-706).  This is the chain of `mpiexec -n %d gmrm`; it costs\n"
+               "       : one kernel launch and one device-to-host copy per marker and shard -- use it to validate, not to produce.\n",
+               nsh, nsh > 1 ? "s" : "", nsh);
+    } else if (nsh > 1) {                                                    // replaces the MPI calls of Bayes::process
         need(gmrm_group_create(&grp, nsh, ctxs.data(), smps.data(), G, K, opt.no_rccl ? 0 : 1), "gmrm_group_create");
         printf("INFO   : %d marker shards, residual exchange once per sweep through %s.\n", nsh,
                gmrm_group_uses_rccl(grp) ? "RCCL (ncclAllReduce)" : "host memory");
@@ -462,8 +475,9 @@ int main(int argc, char** argv) {
         // reference's per-step exchange (bayes.cpp:495-553) -- say so instead of running it silently.
         printf("WARNING: %d shards sweep their blocks against per-shard residual replicas that are reconciled ONCE per sweep.\n"
                "       : This is not the Markov chain of `mpiexec -n %d gmrm` (exchange after every marker step) nor the 1-shard chain;\n"
-               "       : markers in LD that sit in different shards see each other's updates one sweep late.  Use 1 shard for the reference chain.\n",
-               nsh, nsh);
+               "       : markers in LD that sit in different shards see each other's updates one sweep late.  Use 1 shard for the\n"
+               "       : reference's 1-task chain, or --sync-every 1 for its %d-task chain (slow: one exchange per marker step).\n",
+               nsh, nsh, nsh);
     }
 
     // phenotype.cpp:129-143: <out_dir>/<phen stem>.{bet,cpn,csv}
@@ -480,7 +494,8 @@ int main(int argc, char** argv) {
     for (unsigned it = it_first; it <= opt.iterations; it++) {
         const double ts = now();
         printf("\n\n@@@ ITERATION %5d\n", it);
-        if (grp) need(gmrm_group_iterate(grp, (int)it), "gmrm_group_iterate");
+        if (grp && opt.sync_every == 1) need(gmrm_group_iterate_steps(grp, (int)it), "gmrm_group_iterate_steps");
+        else if (grp) need(gmrm_group_iterate(grp, (int)it), "gmrm_group_iterate");
         else need(gmrm_sampler_iterate(smp, (int)it), "gmrm_sampler_iterate");
         for (int t = 0; t < T; t++) {
             gmrm_hyper h;

@@ -117,6 +117,10 @@ int gmrm_dot(gmrm_ctx* ctx, int t, int mloc, double mu, double sigma_inv, double
 /* void Phenotype::update_epsilon(const double* dbeta[3], bed) (src/phenotype.hpp:153,
  * src/phenotype.cpp:326-393); dbeta3 = {dbeta, mave, msig}; the column is marker mloc. */
 int gmrm_update_eps(gmrm_ctx* ctx, int t, int mloc, const double* dbeta3);
+/* Bayes::update_epsilon(counts, dbetas, bed) for one sender (src/bayes.cpp:681-706): the same update with the
+ * column of ANOTHER shard -- marker mloc of context src, which upstream receives through MPI_Allgatherv
+ * (src/bayes.cpp:537-541).  Copied device to device when src sits on another GPU. */
+int gmrm_update_eps_from(gmrm_ctx* ctx, int t, gmrm_ctx* src, int mloc, const double* dbeta3);
 /* void Phenotype::offset_epsilon(double) (src/phenotype.hpp:108, src/phenotype.cpp:395-411) */
 int gmrm_offset_eps(gmrm_ctx* ctx, int t, double offset);
 /* double Phenotype::epsilon_sumsqr() (src/phenotype.hpp:154, src/phenotype.cpp:251-261) */
@@ -175,6 +179,7 @@ int gmrm_get_comp(gmrm_ctx* ctx, int t, int* comp);
 int gmrm_get_acum(gmrm_ctx* ctx, int t, double* acum);
 int gmrm_set_betas(gmrm_ctx* ctx, int t, const double* betas);
 int gmrm_set_comp(gmrm_ctx* ctx, int t, const int* comp);
+int gmrm_set_acum(gmrm_ctx* ctx, int t, const double* acum);
 
 /* ------------------------------------------------------------------------------------
  * Multi-GPU residual exchange (replaces the per-step MPI_Allgatherv of src/bayes.cpp:
@@ -232,6 +237,17 @@ int gmrm_sampler_end_sweep(gmrm_sampler* s, int* cass /*[T*G*K]*/, double* beta_
 int gmrm_sampler_epilogue(gmrm_sampler* s, const int* cass, const double* beta_sqn);
 int gmrm_sampler_adopt(gmrm_sampler* s, int t, const double* sigmag, const double* pi_est, double sigmae);
 int gmrm_sampler_get(gmrm_sampler* s, int t, gmrm_hyper* out);
+/* The reference's per-step schedule (src/bayes.cpp:374-553 as several MPI tasks run it), for callers that want
+ * the chain of `mpiexec -n R gmrm` rather than the sweep kernel's speed: between gmrm_sampler_begin_steps
+ * (bayes.cpp:358-367 with this shard's own mu, nothing launched) and gmrm_sampler_end_steps (effects back to the
+ * device, local cass / beta_sqn as gmrm_sampler_end_sweep), gmrm_sampler_step(mrki) draws the effect of this
+ * shard's mrki-th marker for every phenotype (one gmrm_dot + the host restatement of bayes.cpp:396-492) and
+ * returns *mloc and dbeta3[3t..3t+2] = {dbeta, mave, msig}, zero when nothing changed or mrki >= M.  The residual
+ * is not touched: the caller applies every shard's changed marker to every replica in shard order with
+ * gmrm_update_eps_from (bayes.cpp:681-706).  gmrm_group_iterate_steps does all of that. */
+int gmrm_sampler_begin_steps(gmrm_sampler* s, const double* mu_use /*[T]*/);
+int gmrm_sampler_step(gmrm_sampler* s, int mrki, int* mloc, double* dbeta3 /*[3T]*/);
+int gmrm_sampler_end_steps(gmrm_sampler* s, int* cass /*[T*G*K]*/, double* beta_sqn /*[T*G]*/);
 /* one .csv record of phenotype t as write_ofile_csv formats it (src/xfiles.cpp:17-42) */
 int gmrm_sampler_csv_line(gmrm_sampler* s, int t, int it, char* buf, size_t len);
 /* Checkpoint / restart (no reference counterpart: Bayes::process deletes its outputs at start,
@@ -254,6 +270,9 @@ typedef struct gmrm_group gmrm_group;
 int gmrm_group_create(gmrm_group** out, int n, gmrm_ctx** ctxs, gmrm_sampler** smps, int G, int K, int want_rccl);
 int gmrm_group_uses_rccl(const gmrm_group* g);
 int gmrm_group_iterate(gmrm_group* g, int it);
+/* the same iteration on the reference's per-step schedule (see gmrm_sampler_step): the chain of
+ * `mpiexec -n <shards> gmrm`, at the reference's cost of one exchange per marker step */
+int gmrm_group_iterate_steps(gmrm_group* g, int it);
 int gmrm_group_destroy(gmrm_group* g);
 /* one-rank exercise of the RCCL entry points the group uses (what a one-GPU box can check) */
 int gmrm_rccl_selftest(int device);

@@ -606,16 +606,18 @@ void orc_chain_prologue(orc_chain* c, int it) {
     orc_chain_prologue_apply(c, orc_chain_prologue_draw(c, it));
 }
 
-/* bayes.cpp:384-492 for one marker, then bayes.cpp:681-706 -> phenotype.cpp:326 */
-static void chain_marker_step(orc_chain* c, int mloc) {
+/* bayes.cpp:384-492 for one marker: the Gibbs draw, everything up to (not including) the residual
+ * update.  Returns 1 when the effect changed (share_mrk, bayes.cpp:483-488) with d3 = {dbeta, mave, msig}. */
+static int chain_marker_decide(orc_chain* c, int mloc, double d3[3]) {
     const int K = c->K, N = c->N;
+    d3[0] = d3[1] = d3[2] = 0.0;
     const int mglo = c->S + mloc;
     const int mgrp = c->group_index[mglo];
 
     if (c->sigmag[mgrp] == 0.0) {            /* bayes.cpp:396-400 (no draw, no residual update) */
         c->acum[mloc] = 1.0;
         c->betas[mloc] = 0.0;
-        return;
+        return 0;
     }
     double beta = c->betas[mloc];
     double sige_g = c->sigmae / c->sigmag[mgrp];
@@ -667,8 +669,17 @@ static void chain_marker_step(orc_chain* c, int mloc) {
         }
     }
     dbeta -= c->betas[mloc];
-    if (fabs(dbeta) > 0.0) {                 /* bayes.cpp:483-488, 681-706 */
-        double d3[3] = { dbeta, c->mave[mloc], c->msig[mloc] };
+    if (fabs(dbeta) > 0.0) {                 /* bayes.cpp:483-488 */
+        d3[0] = dbeta; d3[1] = c->mave[mloc]; d3[2] = c->msig[mloc];
+        return 1;
+    }
+    return 0;
+}
+
+/* one marker of a single rank: the draw, then bayes.cpp:681-706 -> phenotype.cpp:326 */
+static void chain_marker_step(orc_chain* c, int mloc) {
+    double d3[3];
+    if (chain_marker_decide(c, mloc, d3)) {
         orc_update_epsilon(c->eps, d3, &c->bed[(size_t)mloc * c->mbytes], c->mask4, c->im4);
         c->n_updates++;
     }
@@ -772,6 +783,61 @@ void orc_ns_iterate(orc_chain** ch, int R, int it) {
         ch[r]->sigmae = ch[0]->sigmae;
     }
     free(start); free(s1); free(s2); free(cass); free(bsq);
+}
+
+/* The reference's own schedule for R ranks holding disjoint marker shards of ONE phenotype
+ * (bayes.cpp:340-651 read as R MPI tasks in one loop):
+ *   prologue  every rank draws AND uses its own mu from its own stream (bayes.cpp:348-358; seeds :796-803),
+ *             so the residual replicas differ by that offset, as upstream's do;
+ *   step mrki of max_r M_r (bayes.cpp:374): every rank with mrki < M_r draws the effect of its marker
+ *             midx_r[mrki] against its own replica (bayes.cpp:381-492); then every replica applies the changed
+ *             markers of ALL ranks in rank order (Allgather/Allgatherv + update_epsilon, bayes.cpp:495-553,
+ *             681-706);
+ *   epilogue  cass summed, beta_sqn summed in rank order (bayes.cpp:575-588), every rank draws the hyper-
+ *             parameters on its own stream and adopts rank 0's (bayes.cpp:626,638,649). */
+void orc_ps_iterate(orc_chain** ch, int R, int it) {
+    const int G = ch[0]->G, K = ch[0]->K;
+    int Mm = 0;
+    for (int r = 0; r < R; r++) {
+        orc_chain_prologue(ch[r], it);
+        if (ch[r]->M > Mm) Mm = ch[r]->M;
+    }
+    double (*d3)[3] = (double (*)[3])malloc(sizeof(double[3]) * (size_t)R);
+    int* share = (int*)malloc(sizeof(int) * (size_t)R);
+    int* mloc = (int*)malloc(sizeof(int) * (size_t)R);
+    for (int mrki = 0; mrki < Mm; mrki++) {
+        for (int r = 0; r < R; r++) {
+            share[r] = 0; mloc[r] = 0;
+            if (mrki < ch[r]->M) {
+                mloc[r] = ch[r]->midx[mrki];
+                share[r] = chain_marker_decide(ch[r], mloc[r], d3[r]);
+                ch[r]->n_updates += share[r];
+            }
+        }
+        for (int dst = 0; dst < R; dst++)
+            for (int r = 0; r < R; r++)
+                if (share[r])
+                    orc_update_epsilon(ch[dst]->eps, d3[r], &ch[r]->bed[(size_t)mloc[r] * ch[r]->mbytes],
+                                       ch[dst]->mask4, ch[dst]->im4);
+    }
+    int* cass = (int*)calloc((size_t)(G * K), sizeof(int));
+    double* bsq = (double*)calloc((size_t)G, sizeof(double));
+    for (int r = 0; r < R; r++) {
+        orc_chain_local_sums(ch[r]);
+        for (int i = 0; i < G * K; i++) cass[i] += ch[r]->cass[i];
+        for (int g = 0; g < G; g++) bsq[g] += ch[r]->beta_sqn[g];
+    }
+    for (int r = 0; r < R; r++) {
+        memcpy(ch[r]->cass, cass, sizeof(int) * (size_t)(G * K));
+        memcpy(ch[r]->beta_sqn, bsq, sizeof(double) * (size_t)G);
+        orc_chain_epilogue(ch[r]);
+    }
+    for (int r = 1; r < R; r++) {
+        memcpy(ch[r]->sigmag, ch[0]->sigmag, sizeof(double) * (size_t)G);
+        memcpy(ch[r]->pi_est, ch[0]->pi_est, sizeof(double) * (size_t)(G * K));
+        ch[r]->sigmae = ch[0]->sigmae;
+    }
+    free(d3); free(share); free(mloc); free(cass); free(bsq);
 }
 
 double* orc_chain_eps(orc_chain* c) { return c->eps; }

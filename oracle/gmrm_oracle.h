@@ -101,6 +101,9 @@ void orc_chain_epilogue(orc_chain* c);             /* bayes.cpp:590-651 */
 /* the build's sweep-synchronous multi-rank schedule (DESIGN.md "Multi-GPU"); not the
  * reference's per-step exchange.  All chains share one phenotype and hold disjoint shards. */
 void orc_ns_iterate(orc_chain** chains, int nranks, int it);
+/* the reference's own per-step multi-rank schedule (bayes.cpp:374-553, 681-706): every rank keeps its own mu,
+ * after every marker step all replicas apply the changed markers of all ranks in rank order. */
+void orc_ps_iterate(orc_chain** chains, int nranks, int it);
 
 /* getters (pointers stay owned by the chain) */
 double* orc_chain_eps(orc_chain* c);

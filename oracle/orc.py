@@ -84,6 +84,7 @@ _SIGS = {
     "orc_chain_local_sums": (None, [C.c_void_p]),
     "orc_chain_epilogue": (None, [C.c_void_p]),
     "orc_ns_iterate": (None, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "orc_ps_iterate": (None, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "orc_chain_eps": (c_double_p, [C.c_void_p]),
     "orc_chain_betas": (c_double_p, [C.c_void_p]),
     "orc_chain_acum": (c_double_p, [C.c_void_p]),
@@ -228,6 +229,12 @@ def ns_iterate(chains, it):
     """The build's sweep-synchronous multi-rank schedule (orc_ns_iterate)."""
     arr = (C.c_void_p * len(chains))(*[c.h for c in chains])
     chains[0].L.orc_ns_iterate(arr, len(chains), int(it))
+
+
+def ps_iterate(chains, it):
+    """The reference's per-step multi-rank schedule, bayes.cpp:374-553 (orc_ps_iterate)."""
+    arr = (C.c_void_p * len(chains))(*[c.h for c in chains])
+    chains[0].L.orc_ps_iterate(arr, len(chains), int(it))
 
 
 def predict_g(bed, mask4, mave, msig, beta):

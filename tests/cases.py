@@ -76,8 +76,11 @@ def prepare_traits(inp):
     return out
 
 
-def run_oracle(case: Case, inp, iters=None, canon=True, nranks=1, seed=None, shuffle=True, mimic_hydra=False):
-    """History of the oracle chain(s): per trait, per iteration comp / betas / hyper-parameters."""
+def run_oracle(case: Case, inp, iters=None, canon=True, nranks=1, seed=None, shuffle=True, mimic_hydra=False,
+               schedule="sweep"):
+    """History of the oracle chain(s): per trait, per iteration comp / betas / hyper-parameters.
+    schedule: "sweep" = the build's once-per-sweep exchange (orc_ns_iterate), "steps" = the reference's exchange
+    after every marker step (orc_ps_iterate, bayes.cpp:495-553); they coincide for nranks == 1."""
     from oracle import orc
     from gmrm_amd.api import block_of_markers
     iters = case.iters if iters is None else iters
@@ -93,7 +96,9 @@ def run_oracle(case: Case, inp, iters=None, canon=True, nranks=1, seed=None, shu
                                     canon=canon))
         h = dict(comp=[], betas=[], sigmae=[], sigmag=[], pi=[], mu=[], m0=[], csv=[], eps=None, nupd=[])
         for it in range(1, iters + 1):
-            if nranks == 1:
+            if schedule == "steps":
+                orc.ps_iterate(chains, it)
+            elif nranks == 1:
                 chains[0].iterate(it)
             else:
                 orc.ns_iterate(chains, it)

@@ -305,3 +305,49 @@ def test_exchange_layout_is_chosen_per_batch(gpu):
     assert np.array_equal(ctx.get_epsilon(0), want[0]["eps"])
     smp.close()
     ctx.close()
+
+
+def test_per_step_calls_and_the_sweep_kernel_are_one_chain(gpu):
+    """gmrm_sampler_begin_steps / _step / _end_steps (the reference's per-marker loop, bayes.cpp:376-492, with the
+    residual update applied by the caller, bayes.cpp:681-706) interleaved with kernel sweeps on ONE shard: iteration 1
+    and 3 through the persistent kernel, 2 and 4 marker by marker.  Every iteration must be the oracle's plain chain
+    bit for bit, acum included: the host restatement of the Gibbs step and the kernel are interchangeable."""
+    from oracle import orc
+    case = cases.CASE_BY_NAME["ragged"]
+    inp = cases.make_inputs(case)
+    traits = cases.prepare_traits(inp)
+    ctx = gmrm_amd.Context(case.N, case.M, T=len(traits))
+    ctx.upload_bed(inp["bed"])
+    for t, (eps, mask4, nonas) in enumerate(traits):
+        ctx.upload_trait(t, eps, mask4, nonas)
+        ctx.compute_markers_statistics(t)
+    smp = gmrm_amd.Sampler(ctx, case.seed, inp["cva"], inp["group_index"])
+    chains = [orc.Chain(case.N, inp["bed"], eps, mask4, nonas, inp["group_index"], inp["cva"], case.seed, canon=True)
+              for eps, mask4, nonas in traits]
+    for it in range(1, 5):
+        if it % 2:
+            smp.iterate(it)
+        else:
+            smp.begin_steps(smp.draw_mu(it))
+            changed = 0
+            for mrki in range(case.M):
+                mloc, d3 = smp.step(mrki)
+                for t in range(len(traits)):
+                    if d3[t, 0] != 0.0:
+                        ctx.update_epsilon_from(ctx, d3[t], mloc, t)
+                        changed += 1
+            mloc, d3 = smp.step(case.M)                      # a task with fewer markers than the longest: shares nothing
+            assert mloc == 0 and not d3.any()
+            cass, bsq = smp.end_steps()
+            smp.epilogue(cass, bsq)
+            assert changed == sum(smp.hyper(t).n_updates for t in range(len(traits))) > 0
+        for t, c in enumerate(chains):
+            c.iterate(it)
+            hy = smp.hyper(t)
+            assert np.array_equal(ctx.betas(t), c.betas) and np.array_equal(ctx.comp(t), c.comp), (it, t)
+            assert np.array_equal(ctx.acum(t), c.acum), (it, t)
+            assert np.array_equal(ctx.get_epsilon(t), c.eps), (it, t)
+            assert hy.sigmae == c.sigmae and hy.mu == c.mu and np.array_equal(hy.pi_est, np.asarray(c.pi_est).reshape(-1))
+            assert smp.csv_line(t, it) == c.csv_line(it)
+    with pytest.raises(gmrm_amd.GmrmError):
+        smp.step(0)                                          # outside begin_steps .. end_steps

@@ -101,6 +101,48 @@ def test_cli_marker_shards_in_one_process(gpu, tmp_path, name, shards):
         assert Path(str(stem) + ".csv").read_bytes() == csv
 
 
+@pytest.mark.parametrize("name,shards", [("ragged", 2), ("k3", 3), ("small", 1)])
+def test_cli_per_step_schedule_is_the_reference_multi_task_chain(gpu, tmp_path, name, shards):
+    """bin/gmrm_hip --sync-every 1: the exchange after every marker step that upstream runs (bayes.cpp:495-553,
+    681-706) -- each shard's own mu and seeds, every changed marker applied to every replica in shard order.
+    Byte for byte against the oracle's statement of that schedule (orc_ps_iterate).  With one shard the result
+    must also be the file set of the ordinary run: the host restatement of the Gibbs step and the persistent
+    kernel are the same chain."""
+    assert BIN.exists(), "bin/gmrm_hip not built (python __graft_entry__.py)"
+    case = cases.CASE_BY_NAME[name]
+    inp = cases.make_inputs(case)
+    inp["cva"] = np.array([[float(f"{v:.5f}") for v in row] for row in inp["cva"]])
+    phens = _write_inputs(tmp_path, case, inp)
+    out = tmp_path / "out"
+    iters = 3
+    base = [str(BIN), "--bed-file", str(tmp_path / "t.bed"), "--dim-file", str(tmp_path / "t.dim"),
+            "--phen-files", ",".join(str(p) for p in phens), "--group-index-file", str(tmp_path / "t.gri"),
+            "--group-mixture-file", str(tmp_path / "t.grm"), "--shuffle-markers", "1", "--seed", str(case.seed),
+            "--iterations", str(iters)]
+    cmd = base + ["--out-dir", str(out), "--sync-every", "1"]
+    if shards > 1:
+        cmd += ["--devices", ",".join(["0"] * shards)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "on the reference's per-step schedule" in r.stdout
+    want = cases.run_oracle(case, inp, iters=iters, canon=True, nranks=shards, schedule="steps")
+    for t, h in enumerate(want):
+        stem = out / f"trait{t}"
+        bet = b"".join([struct.pack("<I", case.M)] + [struct.pack("<I", it) + h["betas"][it - 1].tobytes() for it in range(1, iters + 1)])
+        cpn = b"".join([struct.pack("<I", case.M)] + [struct.pack("<I", it) + h["comp"][it - 1].astype("<i4").tobytes() for it in range(1, iters + 1)])
+        csv = b"".join(h["csv"][it - 1] for it in range(1, iters + 1))
+        assert Path(str(stem) + ".bet").read_bytes() == bet
+        assert Path(str(stem) + ".cpn").read_bytes() == cpn
+        assert Path(str(stem) + ".csv").read_bytes() == csv
+    if shards == 1:
+        plain = tmp_path / "plain"
+        r = subprocess.run(base + ["--out-dir", str(plain)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        for t in range(len(want)):
+            for ext in ("bet", "cpn", "csv"):
+                assert (plain / f"trait{t}.{ext}").read_bytes() == (out / f"trait{t}.{ext}").read_bytes()
+
+
 def test_rccl_entry_points_resolve_and_run(gpu):
     """The C++ shard group binds RCCL with dlopen; on a one-GPU box its entry points can at least be
     exercised with one rank (signatures, enum values, stream handling).  Run in a child process so

@@ -209,6 +209,41 @@ def test_sharded_schedule_single_rank_is_plain_iterate():
     assert np.all(np.isfinite(b[0]["eps"]))
 
 
+def test_per_step_schedule_of_the_reference():
+    """orc_ps_iterate (bayes.cpp:374-553 with several MPI tasks).  One task: it IS the plain chain.  Several: every
+    replica receives the same updates in the same order, so the replicas differ by their own mu only
+    (bayes.cpp:348-358 draws it per task) -- and the chain is neither the 1-task nor the per-sweep-exchange one."""
+    case = cases.CASE_BY_NAME["k3"]
+    inp = cases.make_inputs(case)
+    a = cases.run_oracle(case, inp, iters=3, nranks=1)
+    b = cases.run_oracle(case, inp, iters=3, nranks=1, schedule="steps")
+    for k in ("betas", "comp", "sigmag", "pi"):
+        assert all(np.array_equal(x, y) for x, y in zip(a[0][k], b[0][k])), k
+    assert a[0]["csv"] == b[0]["csv"] and np.array_equal(a[0]["eps"], b[0]["eps"])
+
+    from gmrm_amd.api import block_of_markers
+    eps, mask4, nonas = cases.prepare_traits(inp)[0]
+    chains = []
+    for r in range(3):
+        S, Ml, _ = block_of_markers(case.M, 3, r)
+        chains.append(orc.Chain(case.N, inp["bed"][S:S + Ml], eps, mask4, nonas, inp["group_index"], inp["cva"],
+                                case.seed, Mt=case.M, S=S, rank=r, canon=True))
+    for it in range(1, 4):
+        orc.ps_iterate(chains, it)
+    keep = ~np.asarray(inp["isna"][0], dtype=bool)
+    base = chains[0].eps[:case.N][keep] + chains[0].mu
+    assert len({c.mu for c in chains}) == 3                       # per-task seeds (bayes.cpp:796-803)
+    for c in chains[1:]:
+        assert np.max(np.abs(c.eps[:case.N][keep] + c.mu - base)) < 1e-10
+        assert c.sigmae == chains[0].sigmae and np.array_equal(c.pi_est, chains[0].pi_est)
+    ns = cases.run_oracle(case, inp, iters=3, nranks=3)
+    ps = cases.run_oracle(case, inp, iters=3, nranks=3, schedule="steps")
+    assert np.array_equal(ps[0]["betas"][-1], np.concatenate([c.betas for c in chains]))
+    assert not np.array_equal(ps[0]["betas"][-1], ns[0]["betas"][-1])
+    assert not np.array_equal(ps[0]["betas"][-1], a[0]["betas"][-1])
+    assert 0.1 < ps[0]["sigmae"][-1] < 2.0
+
+
 def test_predict_restatement_against_numpy():
     """Bayes::predict's loops (bayes.cpp:93-122, 172-205, 233-234) as restated in the oracle, checked
     against a direct numpy evaluation of the same formulas on decoded genotypes (no GPU)."""
