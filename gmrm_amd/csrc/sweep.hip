@@ -97,7 +97,8 @@ constexpr int META_POS = 256;                   // per-marker inputs of the samp
 constexpr int L_META = L_TAB + TAB_LDS * 8;     // int m[256], int g[256], double beta[256], mave[256], msig[256]
 constexpr int L_NM   = L_META + META_POS * 32;  // uint8[256]: "no missing genotype" flag of the marker at each ring position
 constexpr int L_TOT  = L_NM + META_POS;         // double[SW_VMAX]: the batch totals as wavefront 0 fetched them
-constexpr int L_PLN  = L_TOT + SW_VMAX * 8;     // uint8[8][PSTRIDE]: digit planes of the residual (operand B order)
+constexpr int L_ZSP  = L_TOT + SW_VMAX * 8;     // int64[16][2]: missing-genotype terms of a batch's few dirty markers (sparse_z)
+constexpr int L_PLN  = L_ZSP + 16 * 16;         // uint8[8][PSTRIDE]: digit planes of the residual (operand B order)
 template <int R> constexpr int l_ring() { return L_PLN + Geo<R>::PLANES; }
 static_assert(L_PLN % 16 == 0, "LDS carve");
 // Request > 80 KiB so that exactly one workgroup fits per CU.
@@ -634,6 +635,22 @@ __device__ __forceinline__ long long quad_sum64(long long x) {
     return y;
 }
 
+// sum of x over the wavefront, in every lane
+__device__ __forceinline__ long long wave_sum64(long long x) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int lo = __shfl_xor((int)x, o, 64), hi = __shfl_xor((int)(x >> 32), o, 64);
+        x += (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    }
+    return x;
+}
+// A batch of a mixed block with at most this many dirty markers (but not all of them dirty) gathers their
+// missing-genotype terms thread by thread instead of running the indicator MFMAs on their tiles.
+#ifndef GM_SPARSE_ZMAX
+#define GM_SPARSE_ZMAX 8
+#endif
+constexpr int SPARSE_ZMAX = GM_SPARSE_ZMAX;
+
 // One super-step's LDS operands: the 64 bytes of the lane's digit plane (operand B of the four MFMAs) and the
 // lane's 16-byte chunk of its marker's slice (operand A before the field masks) for the ONE or TWO tiles the
 // wavefront works on (B is shared by both).  The reads are inline asm so that they can be issued a whole
@@ -710,6 +727,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(smem + L_SUM);
     double* s_red = reinterpret_cast<double*>(smem + L_RED);
     double* s_wsq = reinterpret_cast<double*>(smem + L_WSQ);
+    long long* s_zsp = reinterpret_cast<long long*>(smem + L_ZSP);
     double* s_tab = reinterpret_cast<double*>(smem + L_TAB);
     char* planes = smem + L_PLN;
     const bool tab_in_lds = G * (1 + 3 * K) <= TAB_LDS;
@@ -999,6 +1017,18 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         lds_barrier();                                // ring / plane / meta writes are visible (no vmcnt drain)
         PA(0);
         const int p0 = b.p0;
+        // Everything the scan needs from the meta ring is fetched in ONE burst, for ring positions that may lie behind
+        // the end of the batch (the index is masked; what is not needed is dropped below): a load issued only after
+        // the batch length is known would put a second and a third LDS round trip on the critical path.
+        const int sl0 = (p0 + lane) & (META_POS - 1), sl1 = (p0 + lane + 64) & (META_POS - 1);
+        const double rb0 = mr_beta[sl0], rb1 = mr_beta[sl1];
+        unsigned char rn0 = 1, rn1 = 1;
+        if (MODE == 1) { rn0 = mr_nm[sl0]; rn1 = mr_nm[sl1]; }
+        LaneIn r0i{0, 0, 0.0, 0.0, 1.0}, r1i{0, 0, 0.0, 0.0, 1.0};
+        if (wave == 0) {
+            r0i = LaneIn{mr_m[sl0], mr_g[sl0], rb0, mr_mave[sl0], mr_msig[sl0]};
+            r1i = LaneIn{mr_m[sl1], mr_g[sl1], rb1, mr_mave[sl1], mr_msig[sl1]};
+        }
         // Dirty markers (a missing genotype among the phenotyped individuals) exchange two more values each: the batch
         // is cut where the slots run out.  (Every wavefront reads the same LDS bytes: uniform.)
         unsigned long long dm0 = 0ull, dm1 = 0ull;
@@ -1007,8 +1037,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             dm0 = ~0ull; dm1 = ~0ull;
         }
         if (MODE == 1) {
-            const bool q0 = lane < b.nb && mr_nm[(p0 + lane) & (META_POS - 1)] == 0;
-            const bool q1 = lane + 64 < b.nb && mr_nm[(p0 + lane + 64) & (META_POS - 1)] == 0;
+            const bool q0 = lane < b.nb && rn0 == 0;
+            const bool q1 = lane + 64 < b.nb && rn1 == 0;
             dm0 = __ballot(q0); dm1 = __ballot(q1);
             const int ndall = __popcll(dm0) + __popcll(dm1);
             if (ndall == b.nb) {                      // (uniform) every marker dirty: 4 slots each
@@ -1025,8 +1055,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // the walk is known to stop there: end the batch at the first such marker instead of computing dots
         // behind it that are certain to go stale.  (Every wavefront scans the same LDS words: uniform.)
         {
-            const bool nz0 = lane < b.nb && mr_beta[(p0 + lane) & (META_POS - 1)] != 0.0;
-            const bool nz1 = lane + 64 < b.nb && mr_beta[(p0 + lane + 64) & (META_POS - 1)] != 0.0;
+            const bool nz0 = lane < b.nb && rb0 != 0.0;
+            const bool nz1 = lane + 64 < b.nb && rb1 != 0.0;
             const unsigned long long m0 = __ballot(nz0), m1 = __ballot(nz1);
             const int first = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : b.nb);
             if (first + 1 < b.nb) b.nb = first + 1;
@@ -1040,18 +1070,75 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         b.dm0 = dm0; b.dm1 = dm1;
         const int nd = __popcll(dm0) + __popcll(dm1);
         const bool all_dirty = MODE == 2 || nd == nb; // then the r-th dirty marker is batch position r
-        li0 = LaneIn{0, 0, 0.0, 0.0, 1.0};
-        li1 = LaneIn{0, 0, 0.0, 0.0, 1.0};
-        if (wave == 0 && lane < nb) {
-            const int sl = (p0 + lane) & (META_POS - 1);
-            li0.m = mr_m[sl]; li0.g = mr_g[sl]; li0.beta_old = mr_beta[sl]; li0.mave = mr_mave[sl]; li0.msig = mr_msig[sl];
-        }
-        if (wave == 0 && lane + 64 < nb) {
-            const int sl = (p0 + lane + 64) & (META_POS - 1);
-            li1.m = mr_m[sl]; li1.g = mr_g[sl]; li1.beta_old = mr_beta[sl]; li1.mave = mr_mave[sl]; li1.msig = mr_msig[sl];
+        // A few dirty markers among clean ones: every tile runs the one-MFMA-set pass (X = sum c' d) and the
+        // missing-genotype term Z of each dirty marker is gathered from the digit planes, one wavefront per
+        // marker (sparse_z below), instead of a second MFMA set over every tile that holds such a marker.
+        const bool sparse_z = MODE == 1 && !all_dirty && nd > 0 && nd <= SPARSE_ZMAX;      // uniform
+        {
+            const bool a0 = wave == 0 && lane < nb, a1 = wave == 0 && lane + 64 < nb;
+            li0 = LaneIn{a0 ? r0i.m : 0, a0 ? r0i.g : 0, a0 ? r0i.beta_old : 0.0, a0 ? r0i.mave : 0.0, a0 ? r0i.msig : 1.0};
+            li1 = LaneIn{a1 ? r1i.m : 0, a1 ? r1i.g : 0, a1 ? r1i.beta_old : 0.0, a1 ? r1i.mave : 0.0, a1 ? r1i.msig : 1.0};
         }
         max_nb = nb > max_nb ? nb : max_nb;
         PA(1);
+        if constexpr (MODE == 1) {
+            if (sparse_z) {
+                // Z of a dirty marker = sum over its missing genotypes of the residual's two exact parts as grid
+                // integers -- the integers whose signed base-256 digits are the plane bytes (refresh_planes), so
+                // this is the sum the indicator MFMAs form, term by term:  sum a d = X - 3 Z,  sum b d = (sum d) - Z.
+                // One wavefront per dirty marker: it scans the marker's slice (SB / 4 dwords), and for every field
+                // that reads 11 picks the eight plane bytes of that individual (position 64 chunk + 16 field +
+                // 4 dword + byte, the order of operand B).  No f64 work, nothing that depends on who owns whom.
+                // Done BEFORE the tile passes: its two dependent LDS round trips cost ~100 cycles each now and
+                // several hundred once the four wavefronts stream operands for the MFMAs.
+                unsigned long long r0 = dm0, r1 = dm1;
+                int r = 0;
+#pragma unroll 1
+                while (r0 | r1) {
+                    int m;
+                    if (r0) { m = __ffsll((long long)r0) - 1; r0 &= r0 - 1ull; }
+                    else    { m = 64 + __ffsll((long long)r1) - 1; r1 &= r1 - 1ull; }
+                    if ((r & 3) == wave) {
+                        const int pm = p0 + m;
+                        const char* slice = ring + (size_t)((unsigned)pm % (unsigned)RPOS) * SB;
+                        const int swz = pm & (CPP - 1);
+                        long long z1 = 0, z2 = 0;
+#pragma unroll
+                        for (int q0 = 0; q0 < SB / 4; q0 += 64) {
+                            const int q = q0 + lane;                                      // dword of the stored slice
+                            const uint32_t w = *reinterpret_cast<const uint32_t*>(slice + 4 * q);
+                            uint32_t u = w & (w >> 1) & 0x55555555u;                      // bit 2 i of byte b: field i of byte b reads 11
+                            const int cbase = 64 * ((q >> 2) ^ swz) + 4 * (q & 3);        // logical chunk, dword j
+                            while (u) {                                                   // rare: a handful of calls per slice
+                                const int bit = __ffs((int)u) - 1;
+                                u &= u - 1u;
+                                const int posn = cbase + 16 * ((bit & 7) >> 1) + (bit >> 3);
+                                int v1 = 0, v2 = 0;
+#pragma unroll
+                                for (int n = 0; n < 4; n++) {
+                                    v1 += (int)*reinterpret_cast<const signed char*>(planes + n * PST + posn) << (8 * n);
+                                    v2 += (int)*reinterpret_cast<const signed char*>(planes + (n + 4) * PST + 64 + posn) << (8 * n);
+                                }
+                                z1 += v1; z2 += v2;
+                            }
+                        }
+                        // the few lanes that found something, one by one (a wavefront-wide sum only if there are many)
+                        unsigned long long hm = __ballot((z1 | z2) != 0ll);
+                        long long t1 = 0, t2 = 0;
+                        if (__popcll(hm) > 8) { t1 = wave_sum64(z1); t2 = wave_sum64(z2); }
+                        else
+                            while (hm) {
+                                const int l = __ffsll((long long)hm) - 1;
+                                hm &= hm - 1ull;
+                                t1 += (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(z1 >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)z1, l));
+                                t2 += (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(z2 >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)z2, l));
+                            }
+                        if (lane == 0) { s_zsp[2 * r] = t1; s_zsp[2 * r + 1] = t2; }     // read at the publish, after the barrier
+                    }
+                    r++;
+                }
+            }
+        }
         // work split: nt tiles of 16 markers; the 4 wavefronts = tsplit tile groups x ksplit parts of the slice
         const int nt = (nb + 15) >> 4;
         const int tsplit = nt >= 4 ? 4 : (nt >= 2 ? 2 : 1);
@@ -1152,7 +1239,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         using IC1 = std::integral_constant<int, 1>;
         using IC2 = std::integral_constant<int, 2>;
         // the 16 positions of tile t hold a dirty marker?  (tiles 0..3: dm0, 4..7: dm1)
-        auto tile_dirty = [&](int t) { return (((t < 4 ? dm0 >> (16 * t) : dm1 >> (16 * (t - 4))) & 0xffffull) != 0ull); };
+        auto tile_dirty = [&](int t) { return !sparse_z && (((t < 4 ? dm0 >> (16 * t) : dm1 >> (16 * (t - 4))) & 0xffffull) != 0ull); };
         auto one_pass = [&](auto ns_tag, auto nt_tag, int t, bool dirty) {
             if constexpr (MODE == 0) tile_pass(ns_tag, nt_tag, std::true_type{}, t);
             else if constexpr (MODE == 2) tile_pass(ns_tag, nt_tag, std::false_type{}, t);
@@ -1182,6 +1269,12 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 tot = s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2];
             } else {
                 long long v = (long long)s_sum[tid];
+                if constexpr (MODE == 1) {
+                    if (sparse_z) {                   // X - 3 Z for the a-sums of a dirty marker, -Z in its own b-slots
+                        if (tid >= 2 * nb + 2) v -= s_zsp[tid - (2 * nb + 2)];
+                        else if (dirty_at(dm0, dm1, tid >> 1)) v -= 3 * s_zsp[2 * dirty_rank(dm0, dm1, tid >> 1) + (tid & 1)];
+                    }
+                }
                 if (tid >= 2 * nb + 2) {              // dirty marker: sum b d = sum d - Z, this slice's sum of the exact part as an integer
                     const int w2 = tid & 1;
                     const double dsum = s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2];

@@ -275,17 +275,19 @@ def test_many_groups_tables_beyond_the_lds_budget(gpu, G, K):
     cases.assert_same_history(got, want, exact=True)
 
 
-def test_exchange_layout_is_chosen_per_batch(gpu):
-    """Only SOME markers have missing genotypes (a genotyping array with a few poorly called SNPs): the kernel
-    cuts the visit order into runs of one kind and uses the 2-value exchange layout for the clean runs, the
-    4-value layout for the others (round 1 put the whole launch on the 4-value layout as soon as one marker had a
-    missing genotype).  Results do not depend on the layout: bit-exact against the oracle; both layouts occur."""
+@pytest.mark.parametrize("one_in,calls", [(8, (1, 40)), (40, (300, 3000)), (3, (1, 400))])
+def test_exchange_layout_is_chosen_per_batch(gpu, one_in, calls):
+    """Only SOME markers have missing genotypes (a genotyping array with a few poorly called SNPs): clean markers
+    exchange 2 values, dirty ones 4, inside one batch (round 1 put the whole launch on the 4-value layout as soon as
+    one marker had a missing genotype).  A batch with a few dirty markers gathers their missing-genotype terms
+    thread by thread (few calls: one LDS add per call; many: one per wavefront), one with many runs the indicator
+    MFMAs on their tiles.  Results do not depend on any of that: bit-exact against the oracle; clean batches occur."""
     case = cases.Case("mixed", 30_000, 1500, 2, 4, 1, 0.0, 150, 77, 3, 30)
     inp = cases.make_inputs(case)
     rng = np.random.default_rng(5)
-    dirty = rng.choice(case.M, size=case.M // 8, replace=False)          # 12 % of the markers get missing genotypes
+    dirty = rng.choice(case.M, size=case.M // one_in, replace=False)     # these markers get missing genotypes
     for m in dirty:
-        who = rng.choice(case.N, size=int(rng.integers(1, 40)), replace=False)
+        who = rng.choice(case.N, size=int(rng.integers(*calls)), replace=False)
         for i in who:
             b, k = divmod(int(i), 4)
             inp["bed"][m, b] = (int(inp["bed"][m, b]) & (0xFF ^ (3 << (2 * k)))) | (1 << (2 * k))     # code 01 = missing
@@ -301,7 +303,7 @@ def test_exchange_layout_is_chosen_per_batch(gpu):
         assert np.array_equal(ctx.betas(0), want[0]["betas"][it - 1])
         hy = smp.hyper(0)
         assert hy.sigmae == want[0]["sigmae"][it - 1]
-        assert 0 < hy.n_fast_batches < hy.n_batches, (hy.n_fast_batches, hy.n_batches)
+        assert hy.n_fast_batches < hy.n_batches and (one_in < 8 or hy.n_fast_batches > 0), (hy.n_fast_batches, hy.n_batches)
     assert np.array_equal(ctx.get_epsilon(0), want[0]["eps"])
     smp.close()
     ctx.close()
