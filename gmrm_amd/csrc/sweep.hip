@@ -382,10 +382,32 @@ struct Totals { double t0, t1, t2, t3; };
 #define SSTAMP(i) do { } while (0)
 #endif
 
+// The uniform draws of a batch (bayes.cpp:435, one per marker whose group has sigmaG != 0) do not depend on the
+// dots: which word of the stream a marker gets follows from the cursor the previous batch left and the sigmaG
+// flags of the markers before it.  Wavefront 0 looks them up BEFORE it polls for the totals, so that the table
+// read, the ballot and the read of the stream (two dependent LDS round trips) are off the critical path.
+// p1 is the draw of position 64 + lane provided the walk gets past position 63.
+struct Draws { double p0, p1; };
+template <class TP>
+__device__ __forceinline__ Draws sample_prepare(int nb, char* smem, TP tab, int g0, int g1) {
+    const int lane = threadIdx.x & 63;
+    const int* ctl = reinterpret_cast<const int*>(smem + L_CTL);
+    const LdsStream rs{reinterpret_cast<const uint32_t*>(smem + L_RNG0), reinterpret_cast<const uint32_t*>(smem + L_RNG1), 0, nullptr};
+    const int cursor = ctl[C_CURSOR];
+    const bool use0 = lane < nb && tab[g0] != 0.0;
+    const bool use1 = lane + 64 < nb && tab[g1] != 0.0;
+    const unsigned long long um0 = __ballot(use0), um1 = __ballot(use1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    Draws d;
+    d.p0 = unif_from_word(rs.peek(cursor + __popcll(um0 & below)));
+    d.p1 = unif_from_word(rs.peek(cursor + __popcll(um0) + __popcll(um1 & below)));
+    return d;
+}
+
 template <int K, class TP>
 __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
                                                   const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
-                                                  double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer) {
+                                                  const Draws draws, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer) {
     const int lane = threadIdx.x & 63;
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     double* s_val = reinterpret_cast<double*>(smem + L_VAL);
@@ -419,7 +441,7 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
         const unsigned long long use_mask = __ballot(use);
         const int prefix = __popcll(use_mask & ((1ull << lane) - 1ull));
         const int cursor0 = cursor;
-        const double prob = unif_from_word(rs.peek(cursor0 + prefix));   // bayes.cpp:435
+        const double prob = part ? draws.p1 : draws.p0;                  // bayes.cpp:435: word cursor0 + prefix of the stream (sample_prepare)
 
         SSTAMP(0);   // inputs, RNG peek
         int kc = 0;
@@ -515,8 +537,8 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
 template <int K, class TP>
 __device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
                                           const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
-                                          double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer) {
-    sample_batch_body<K>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tot0, tot1, sigmae, inv2sige, nm1, out, writer);
+                                          double p0, double p1, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer) {
+    sample_batch_body<K>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tot0, tot1, Draws{p0, p1}, sigmae, inv2sige, nm1, out, writer);
 }
 
 // rank of batch position p among the dirty markers of the batch (dm0: positions 0..63, dm1: 64..127)
@@ -1383,6 +1405,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
             Totals tot0{0.0, 0.0, 0.0, 0.0}, tot1{0.0, 0.0, 0.0, 0.0};
+            const Draws draws = tab_in_lds ? sample_prepare(cur.nb, smem, (TabLds)s_tab, li_cur0.g, li_cur1.g)
+                                           : sample_prepare(cur.nb, smem, (TabGlobal)a.sigmag, li_cur0.g, li_cur1.g);
             const bool okw = poll_totals(cur.nb, cur.nv, cur.dm0, cur.dm1, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word, spin_limit);
             if (lane == 0) *reinterpret_cast<volatile int*>(&ctl[C_TOTF]) = (int)(cur.gen + 1u);   // the loaders may start
             TRACE(3);
@@ -1392,19 +1416,19 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 // ONE copy of the step per table address space (only one of them runs in a launch)
                 auto run_step = [&](auto tabq) {
                     if (K == 4) {
-                        sample_batch_body<4>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0);
+                        sample_batch_body<4>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, draws, a.sigmae, a.inv2sige, a.nm1, so, wg == 0);
                     } else {
                         // out-of-line copies take their inputs by address: hand them copies, so that the
                         // loop-carried lane inputs themselves stay in registers (no scratch round trips)
                         const LaneIn lc0 = li_cur0, lc1 = li_cur1;
                         const Totals tc0 = tot0, tc1 = tot1;
                         switch (K) {
-                            case 2: sample_batch<2>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                            case 3: sample_batch<3>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                            case 5: sample_batch<5>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                            case 6: sample_batch<6>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                            case 7: sample_batch<7>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                            default: sample_batch<8>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            case 2: sample_batch<2>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            case 3: sample_batch<3>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            case 5: sample_batch<5>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            case 6: sample_batch<6>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            case 7: sample_batch<7>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            default: sample_batch<8>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
                         }
                     }
                 };
