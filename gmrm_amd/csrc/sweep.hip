@@ -98,7 +98,8 @@ constexpr int L_META = L_TAB + TAB_LDS * 8;     // int m[256], int g[256], doubl
 constexpr int L_NM   = L_META + META_POS * 32;  // uint8[256]: "no missing genotype" flag of the marker at each ring position
 constexpr int L_TOT  = L_NM + META_POS;         // double[SW_VMAX]: the batch totals as wavefront 0 fetched them
 constexpr int L_ZSP  = L_TOT + SW_VMAX * 8;     // int64[16][2]: missing-genotype terms of a batch's few dirty markers (sparse_z)
-constexpr int L_PLN  = L_ZSP + 16 * 16;         // uint8[8][PSTRIDE]: digit planes of the residual (operand B order)
+constexpr int L_ZNX  = L_ZSP + 16 * 16;         // double[129] (+ pad): the x table of the normal ziggurat (gm_rng.h), copied at kernel start
+constexpr int L_PLN  = L_ZNX + 130 * 8;         // uint8[8][PSTRIDE]: digit planes of the residual (operand B order)
 template <int R> constexpr int l_ring() { return L_PLN + Geo<R>::PLANES; }
 static_assert(L_PLN % 16 == 0, "LDS carve");
 // Request > 80 KiB so that exactly one workgroup fits per CU.
@@ -382,6 +383,45 @@ struct Totals { double t0, t1, t2, t3; };
 #define SSTAMP(i) do { } while (0)
 #endif
 
+// gm_rng.h's unit_normal / norm with the layer table x read from LDS: the table sits in global memory otherwise,
+// behind an L1 that the genotype stream keeps flushing, and the stopping lane's draw (two dependent look-ups)
+// waits for L2 on the round's critical path.  Same operations on the same values; the wedge and tail cases
+// (a few per cent of the draws) keep using the tables in global memory.
+template <class Src> __device__ __forceinline__ double unit_normal_lx(Src& s, TabLds znx) {
+    for (;;) {
+        int b;
+        const double x01 = int_float_pair(s, b);
+        const int sign = (b & 1) * 2 - 1;
+        const int i = b >> 1;
+        const double xi = znx[i], xi1 = znx[i + 1];
+        const double x = x01 * xi;
+        if (x < xi1) return x * sign;
+        if (i == 0) {
+            const double tail_start = znx[1];
+            for (;;) {
+                const double xx = unit_exponential(s) / tail_start;
+                const double yy = unit_exponential(s);
+                if (2.0 * yy > xx * xx) return (xx + tail_start) * sign;
+            }
+        }
+        const double y01 = u01(s);
+        const double y = GM_ZNY[i] + y01 * (GM_ZNY[i + 1] - GM_ZNY[i]);
+        double y_above_ubound, y_above_lbound;
+        if (xi >= 1.0) {
+            y_above_ubound = (xi - xi1) * y01 - (xi - x);
+            y_above_lbound = y - (GM_ZNY[i] + (xi - x) * GM_ZNY[i] * xi);
+        } else {
+            y_above_lbound = (xi - xi1) * y01 - (xi - x);
+            y_above_ubound = y - (GM_ZNY[i] + (xi - x) * GM_ZNY[i] * xi);
+        }
+        if (y_above_ubound < 0.0 && (y_above_lbound < 0.0 || y < exp_(-(x * x / 2.0)))) return x * sign;
+    }
+}
+template <class Src> __device__ __forceinline__ double norm_lx(Src& s, double mean, double sigma2, TabLds znx) {
+    const double sigma = __builtin_sqrt(sigma2);
+    return unit_normal_lx(s, znx) * sigma + mean;
+}
+
 // The uniform draws of a batch (bayes.cpp:435, one per marker whose group has sigmaG != 0) do not depend on the
 // dots: which word of the stream a marker gets follows from the cursor the previous batch left and the sigmaG
 // flags of the markers before it.  Wavefront 0 looks them up BEFORE it polls for the totals, so that the table
@@ -484,7 +524,7 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
         if (s < nbp && lane == s) {                                      // the stopping marker
             rs.cursor = cursor0 + prefix + 1;
             double beta_new = 0.0;
-            if (kc > 0) beta_new = norm(rs, muk_c, sigmae / denom_c);    // bayes.cpp:455
+            if (kc > 0) beta_new = norm_lx(rs, muk_c, sigmae / denom_c, (TabLds)reinterpret_cast<const double*>(smem + L_ZNX));   // bayes.cpp:455
             const double dbeta = beta_old - beta_new;                    // bayes.cpp:479
             int upd = 0;
             if (fabs(dbeta) > 0.0) {                                     // bayes.cpp:483, phenotype.cpp:328-329,388
@@ -767,6 +807,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #ifdef GM_SWEEP_PROF
     if (tid < 8) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[tid] = 0ull;
 #endif
+    if (tid < 129) reinterpret_cast<double*>(smem + L_ZNX)[tid] = GM_ZNX[tid];
     if (tid == 0) {
         ctl[C_CURSOR] = *a.rng_index;
         ctl[C_RNGERR] = 0;
