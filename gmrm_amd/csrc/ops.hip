@@ -14,6 +14,7 @@
 // sums are accumulated on pre-rounded bins (gm_common.h split2), hence exactly and in any
 // order, so the f64 atomics that combine workgroups do not make results run-dependent.
 #include "gm_common.h"
+#include <type_traits>
 #include "gm_rng.h"
 #include "gm_internal.h"
 
@@ -305,32 +306,36 @@ struct DevMt {                                        // a plain mt19937 in regi
 // ---- Bayes::predict (src/bayes.cpp:16-284), SURVEY section 8f-3 ---------------------------------
 // g_i = sum over this block's markers, in marker order, of ((a - mave) * b * na * msig) * beta_m
 // (bayes.cpp:113-122; the "transposed" use of the genotype table).  Thread = 8 individuals kept in
-// registers for the whole pass; markers with a zero mean effect add +-0 and are skipped.  The four
+// registers for the whole pass; markers with a zero mean effect add +0.  The four
 // values a marker can add (one per genotype code, computed exactly as the reference's expression) are
 // staged in LDS per chunk of U markers and picked by code with ONE ds_read per individual: the 4-way
 // register select it replaces cost 6 v_cndmask per individual and made the kernel VALU-bound
 // (233 GB/s at 500k x 1M; profiles/README.md).
+// BW = bytes of every column per thread (4 BW individuals): 1 gives twice the wavefronts of 2 for the same work --
+// at 500k individuals that is two per SIMD instead of one, which is what hides the LDS latency.
+template <int BW>
 __global__ __launch_bounds__(256) void k_predict_g(const uint8_t* __restrict__ bed, const uint8_t* __restrict__ namask2,
                                                    size_t stride, int M, const double* __restrict__ mave,
                                                    const double* __restrict__ msig, const double* __restrict__ beta,
                                                    double* __restrict__ g) {
     constexpr int U = 32;                                           // column words in flight per thread (HBM latency)
+    constexpr int NI = 4 * BW;                                      // individuals per thread
+    typedef typename std::conditional<BW == 1, uint8_t, uint16_t>::type word_t;
     __shared__ double s_tv[2][U][4];                                // [chunk parity][marker of the chunk][genotype code]
-    __shared__ int s_nz[2][U];
-    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;          // 2-byte word of every column (8 individuals)
-    const bool live = w * 2 < stride;                                 // (threads beyond the column still help with the tables)
-    const uint32_t nam = live ? reinterpret_cast<const uint16_t*>(namask2)[w] : 0u;
-    const uint32_t keep = nam, force = ~nam & 0x5555u;
-    double acc[8];
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;          // BW-byte word of every column
+    const bool live = w * BW < stride;                                // (threads beyond the column still help with the tables)
+    const uint32_t nam = live ? reinterpret_cast<const word_t*>(namask2)[w] : 0u;
+    const uint32_t keep = nam, force = ~nam & (BW == 1 ? 0x55u : 0x5555u);
+    double acc[NI];
 #pragma unroll
-    for (int i = 0; i < 8; i++) acc[i] = 0.0;
+    for (int i = 0; i < NI; i++) acc[i] = 0.0;
     int par = 0;
     for (int m0 = 0; m0 < M; m0 += U, par ^= 1) {
         uint32_t wd[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int m = m0 + u < M ? m0 + u : M - 1;
-            wd[u] = live ? reinterpret_cast<const uint16_t*>(bed + (size_t)m * stride)[w] : 0u;
+            wd[u] = live ? reinterpret_cast<const word_t*>(bed + (size_t)m * stride)[w] : 0u;
         }
         if (threadIdx.x < U * 4) {                                  // one (marker, code) entry per thread
             const int u = threadIdx.x >> 2, c = threadIdx.x & 3;
@@ -339,21 +344,25 @@ __global__ __launch_bounds__(256) void k_predict_g(const uint8_t* __restrict__ b
             double tv = 0.0;
             if (bm != 0.0) tv = (((code_a(c) - mave[m]) * code_b(c)) * msig[m]) * bm;
             s_tv[par][u][c] = tv;
-            if (c == 0) s_nz[par][u] = bm != 0.0;
         }
         __syncthreads();                                            // one barrier per chunk: the other parity is free by now
+        // No test per marker: a marker with a zero effect (or behind the end of the block) adds +0.0, which leaves
+        // an accumulator as it is (an accumulator is never -0.0: it starts at +0.0 and x + (-x) rounds to +0.0), and a
+        // wave-uniform branch per marker would keep the scheduler from issuing the next marker's table reads
+        // under this one's additions -- the kernel is bound by exactly those LDS reads.  (A 16-entry table per
+        // marker that serves two individuals with one 16-byte read was measured: 0.82 TB/s against 1.08.)
+        const char* tvb = reinterpret_cast<const char*>(&s_tv[par][0][0]);
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            if (s_nz[par][u]) {                                     // uniform over the workgroup
-                const uint32_t x = (wd[u] & keep) | force;
+            const uint32_t x = (wd[u] & keep) | force;
 #pragma unroll
-                for (int i = 0; i < 8; i++) acc[i] += s_tv[par][u][(x >> (2 * i)) & 3u];
-            }
+            for (int i = 0; i < NI; i++)
+                acc[i] += *reinterpret_cast<const double*>(tvb + u * 32 + (((x >> (2 * i)) & 3u) << 3));
         }
     }
     if (live) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) g[8 * w + i] = acc[i];
+        for (int i = 0; i < NI; i++) g[NI * w + i] = acc[i];
     }
 }
 
@@ -427,9 +436,12 @@ hipError_t launch_selftest(int op, const double* x, double* y, int n, hipStream_
 
 hipError_t launch_predict_g(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* mave,
                             const double* msig, const double* beta, double* g, hipStream_t st) {
-    const size_t words = stride / 2;
-    if (words == 0 || M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_predict_g, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, bed, namask2, stride, M, mave, msig, beta, g);
+    if (stride == 0 || M <= 0) return hipSuccess;
+    // two bytes per thread only when that alone fills the SIMDs twice over (256 CUs x 4 SIMDs x 2 wavefronts)
+    if (stride / 2 >= (size_t)256 * 4 * 2 * 64)
+        hipLaunchKernelGGL(k_predict_g<2>, dim3((unsigned)((stride / 2 + 255) / 256)), dim3(256), 0, st, bed, namask2, stride, M, mave, msig, beta, g);
+    else
+        hipLaunchKernelGGL(k_predict_g<1>, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, bed, namask2, stride, M, mave, msig, beta, g);
     return hipGetLastError();
 }
 hipError_t launch_assoc(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* y,
