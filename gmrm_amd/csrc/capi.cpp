@@ -500,9 +500,11 @@ int gmrm_assoc(gmrm_ctx* c, int t, const double* yk, double* xtx, double* xty) {
     Trait& tr = c->tr[t];
     HIPCHK(hipSetDevice(c->device));
     double *d_y = nullptr, *d_xx = nullptr, *d_xy = nullptr;
+    void* d_ws = nullptr;
     int rc = GMRM_OK;
     hipError_t e = hipSuccess;
     do {
+        if ((e = hipMalloc(&d_ws, assoc_workspace_bytes(c->stride))) != hipSuccess) break;
         if ((e = dalloc(&d_xx, (size_t)std::max(1, c->M))) != hipSuccess) break;
         if ((e = dalloc(&d_xy, (size_t)std::max(1, c->M))) != hipSuccess) break;
         const double* ysrc = tr.eps;                                   // default: the residual as it stands
@@ -513,7 +515,7 @@ int gmrm_assoc(gmrm_ctx* c, int t, const double* yk, double* xtx, double* xty) {
             ysrc = d_y;
         }
         if ((e = hipDeviceSynchronize()) != hipSuccess) break;
-        if ((e = launch_assoc(c->bed, tr.namask2, c->stride, c->M, ysrc, d_xx, d_xy, tr.stream)) != hipSuccess) break;
+        if ((e = launch_assoc(c->bed, tr.namask2, c->stride, c->M, ysrc, d_xx, d_xy, d_ws, tr.stream)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(tr.stream)) != hipSuccess) break;
         if (c->M > 0) {
             if ((e = hipMemcpy(xtx, d_xx, (size_t)c->M * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) break;
@@ -521,6 +523,7 @@ int gmrm_assoc(gmrm_ctx* c, int t, const double* yk, double* xtx, double* xty) {
         }
     } while (0);
     if (e != hipSuccess) rc = hip_fail(e, "gmrm_assoc");
+    if (d_ws) (void)hipFree(d_ws);
     if (d_y) (void)hipFree(d_y);
     if (d_xx) (void)hipFree(d_xx);
     if (d_xy) (void)hipFree(d_xy);

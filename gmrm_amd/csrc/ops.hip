@@ -366,50 +366,181 @@ __global__ __launch_bounds__(256) void k_predict_g(const uint8_t* __restrict__ b
     }
 }
 
-// Per marker: xtx = sum (a*b*na)^2 (an integer: #(a=1) + 4 #(a=2)), xty = sum a*b*na*y_i
-// (bayes.cpp:188-196).  One wavefront per AB consecutive markers: a y word (16 doubles, served from
-// L2) is loaded once and used for all of them, so the L2 traffic is 8N/AB bytes per marker.
-constexpr int AB = 8;
-__global__ __launch_bounds__(256) void k_assoc(const uint8_t* __restrict__ bed, const uint8_t* __restrict__ namask2,
-                                               size_t stride, int M, const double* __restrict__ y,
-                                               double* __restrict__ xtx, double* __restrict__ xty) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m0 = (blockIdx.x * 4 + wave) * AB;
-    if (m0 >= M) return;
-    const uint32_t* msk = reinterpret_cast<const uint32_t*>(namask2);
-    const size_t nw = stride / 4;
-    int n1[AB], n2[AB];
-    double s[AB];
+// Per marker: xtx = sum (a*b*na)^2 (an integer: #(a=1) + 4 #(a=2)), xty = sum a*b*na*y_i (bayes.cpp:188-196).
+// Round 1 did this with one wavefront per 8 markers and a 3-way select + FMA per genotype: VALU-bound at 0.8 TB/s.
+// ---- k_assoc on the matrix cores ----------------------------------------------------------------------------------
+// xty_m = sum_i a_im y_i is the sweep kernel's phase A with y in the place of the residual (sweep.hip, "phase A
+// building blocks"): y is scaled by a power of two into (-2^8, 2^8), cut into two exact parts (split2) and those into
+// eight signed base-256 digit planes, one byte per individual, in the order the B operand of v_mfma_i32_16x16x64_i8
+// wants (position 16 i + 4 j + b of a 64-individual chunk <- individual 16 j + 4 b + i); a wavefront turns the
+// 16-byte chunks of 2 x 16 columns into 2-bit fields holding a (one v_and per field and register) and accumulates
+// int32 sums of a * digit per plane.  The result is the EXACT sum of the two parts, rounded once -- closer to the
+// real number than the reference's left-to-right f64 sum (tests: 1e-12 relative).  xtx (= #(a=1) + 4 #(a=2)) comes
+// from two popcounts per dword.  The genotype columns are read once, 16 bytes per lane; the planes of a 2048-individual
+// block are staged in LDS for the four wavefronts (32 markers each) of a workgroup.
+constexpr int AS_BLK = 512;                       // column bytes per block
+constexpr int AS_SS = AS_BLK / 64;                // super-steps (256 individuals) per block
+constexpr int AS_PST = 4 * AS_BLK + 16;           // LDS bytes per plane: the offsets of sweep.hip's Geo<R>::PSTRIDE (bank spreading)
+constexpr int AS_PLN = 8 * AS_PST + 64;
+constexpr int AS_MW = 32, AS_MB = 4 * AS_MW;      // markers per wavefront / per workgroup
+typedef int as_v4i __attribute__((ext_vector_type(4)));
+
+__global__ void k_absmax(const double* __restrict__ y, size_t n, unsigned long long* __restrict__ out) {
+    unsigned long long m = 0ull;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(y[i]));
+        m = b > m ? b : m;                         // |y| as bits: monotone for finite values; NaN / Inf end up on top
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long v = ((unsigned long long)(unsigned)__shfl_xor((int)(m >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)m, o, 64);
+        m = v > m ? v : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+// the power of two that brings max |y| (given as bits) below 2^8
+__device__ __forceinline__ int assoc_shift(unsigned long long maxbits) {
+    const int ex = (int)((maxbits >> 52) & 0x7ffull);
+    return ex == 0 ? 0 : 6 - (ex - 1023);
+}
+// thread = four consecutive POSITIONS of a plane (one dword of each of the eight planes)
+__global__ void k_yplanes(const double* __restrict__ y, const uint8_t* __restrict__ namask2, size_t stride,
+                          const unsigned long long* __restrict__ maxbits, uint8_t* __restrict__ planes, size_t npad) {
+    const size_t tau = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (4 * tau >= npad) return;
+    const size_t c = tau >> 4;
+    const int i = (int)(tau >> 2) & 3, j = (int)tau & 3;
+    const int sh = assoc_shift(*maxbits);
+    const bool nonfinite = ((*maxbits >> 52) & 0x7ffull) == 0x7ffull;
+    uint32_t pl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < AB; k++) { n1[k] = 0; n2[k] = 0; s[k] = 0.0; }
-    for (size_t w = lane; w < nw; w += 64) {
-        const uint32_t nam = msk[w];
-        uint32_t x[AB];
+    for (int b = 0; b < 4; b++) {
+        const size_t ind = 64 * c + 16 * (size_t)j + 4 * (size_t)b + (size_t)i;
+        double v = 0.0;
+        if ((ind >> 2) < stride && ((namask2[ind >> 2] >> (2 * (ind & 3))) & 3u) == 3u) v = y[ind];
+        double q1, q2;
+        split2(nonfinite ? 0.0 : __builtin_ldexp(v, sh), q1, q2);
+        const uint32_t z1 = ((uint32_t)(int)(q1 * 0x1p22) + 0x00808080u) ^ 0x00808080u;   // signed base-256 digits
+        const uint32_t z2 = ((uint32_t)(int)(q2 * 0x1p53) + 0x00808080u) ^ 0x00808080u;
 #pragma unroll
-        for (int k = 0; k < AB; k++) {
-            const int m = m0 + k < M ? m0 + k : M - 1;
-            x[k] = (reinterpret_cast<const uint32_t*>(bed + (size_t)m * stride)[w] & nam) | (~nam & 0x55555555u);
-        }
-        double yw[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) yw[i] = y[16 * w + i];
-#pragma unroll
-        for (int k = 0; k < AB; k++) {
-            const uint32_t lo = x[k] & 0x55555555u, hi = (x[k] >> 1) & 0x55555555u;
-            n2[k] += __popc(~lo & ~hi & 0x55555555u);               // code 00: a = 2
-            n1[k] += __popc(~lo & hi);                               // code 10: a = 1
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const uint32_t c = (x[k] >> (2 * i)) & 3u;
-                s[k] += (c == 0 ? 2.0 : (c == 2 ? 1.0 : 0.0)) * yw[i];
-            }
+        for (int n = 0; n < 4; n++) {
+            pl[n] |= ((z1 >> (8 * n)) & 0xffu) << (8 * b);
+            pl[n + 4] |= ((z2 >> (8 * n)) & 0xffu) << (8 * b);
         }
     }
 #pragma unroll
-    for (int k = 0; k < AB; k++) {
-        const int a1 = wave_sum_i(n1[k]), a2 = wave_sum_i(n2[k]);
-        const double t = wave_sum(s[k]);
-        if (lane == 0 && m0 + k < M) { xtx[m0 + k] = (double)((long long)a1 + 4ll * a2); xty[m0 + k] = t; }
+    for (int n = 0; n < 8; n++) reinterpret_cast<uint32_t*>(planes + (size_t)n * npad)[tau] = pl[n];
+}
+
+__global__ __launch_bounds__(256) void k_assoc_mfma(const uint8_t* __restrict__ bed, const uint8_t* __restrict__ namask2,
+                                                    size_t stride, int M, const uint8_t* __restrict__ planes, size_t npad,
+                                                    const unsigned long long* __restrict__ maxbits,
+                                                    double* __restrict__ xtx, double* __restrict__ xty) {
+    __shared__ __attribute__((aligned(16))) char s_pl[2][AS_PLN];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int mrow = lane & 15, kg = lane >> 4;
+    const int mbase = blockIdx.x * AS_MB + wave * AS_MW;
+    const uint8_t* col[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int m = mbase + 16 * q + mrow;
+        col[q] = bed + (size_t)(m < M ? m : M - 1) * stride;
+    }
+    const size_t nchunk = stride / 16;                               // the column stride is a multiple of 16
+    const int nblk = (int)((stride + AS_BLK - 1) / AS_BLK);
+    // the planes of block 0 -> LDS buffer 0 (thread t: 8 bytes of every plane)
+    uint2 pb[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) pb[n] = *reinterpret_cast<const uint2*>(planes + (size_t)n * npad + 8 * (size_t)tid);
+#pragma unroll
+    for (int n = 0; n < 8; n++) *reinterpret_cast<uint2*>(s_pl[0] + n * AS_PST + (n >> 2) * 64 + 8 * tid) = pb[n];
+    as_v4i acc0[2], acc1[2], acc2[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) { acc0[q] = as_v4i{0, 0, 0, 0}; acc1[q] = as_v4i{0, 0, 0, 0}; acc2[q] = as_v4i{0, 0, 0, 0}; }
+    int n1[2] = {0, 0}, n2[2] = {0, 0};
+    constexpr uint32_t M0 = 0x03030303u, LO = 0x55555555u;
+    // a rolling window of AS_SS super-steps of column chunks: a chunk is requested again (for the next block) as soon
+    // as it has been used, so that a block's worth of loads is always in flight
+    uint4 wa[AS_SS][2], wn[AS_SS];
+    auto request = [&](int blk, int s) {
+        const size_t ci = (size_t)blk * (AS_BLK / 16) + 4 * (size_t)s + (size_t)kg;
+        const bool in = ci < nchunk;
+        wn[s] = in ? *reinterpret_cast<const uint4*>(namask2 + 16 * ci) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int q = 0; q < 2; q++) wa[s][q] = in ? *reinterpret_cast<const uint4*>(col[q] + 16 * ci) : make_uint4(0u, 0u, 0u, 0u);
+    };
+#pragma unroll
+    for (int s = 0; s < AS_SS; s++) request(0, s);
+    for (int blk = 0; blk < nblk; blk++) {
+        const int par = blk & 1;
+        __syncthreads();                                             // buffer par is complete; buffer par ^ 1 is free
+        if (blk + 1 < nblk) {
+#pragma unroll
+            for (int n = 0; n < 8; n++)
+                pb[n] = *reinterpret_cast<const uint2*>(planes + (size_t)n * npad + (size_t)(blk + 1) * 4 * AS_BLK + 8 * (size_t)tid);
+        }
+        const char* pbase = s_pl[par] + (lane & 7) * AS_PST + ((lane & 7) >> 2) * 64 + kg * 64;
+#pragma unroll
+        for (int s = 0; s < AS_SS; s++) {
+            const as_v4i b0 = *reinterpret_cast<const as_v4i*>(pbase + s * 256);
+            const as_v4i b1 = *reinterpret_cast<const as_v4i*>(pbase + s * 256 + 16);
+            const as_v4i b2 = *reinterpret_cast<const as_v4i*>(pbase + s * 256 + 32);
+            const as_v4i b3 = *reinterpret_cast<const as_v4i*>(pbase + s * 256 + 48);
+            const uint32_t nm[4] = {wn[s].x, wn[s].y, wn[s].z, wn[s].w};
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t w4[4] = {wa[s][q].x, wa[s][q].y, wa[s][q].z, wa[s][q].w};
+                uint32_t f[4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t x = (w4[d] & nm[d]) | (~nm[d] & LO);      // NA individuals read "missing" (01)
+                    const uint32_t nl = ~x & LO;                             // low bit clear: codes 00 (a = 2) and 10 (a = 1)
+                    const uint32_t t1 = (x >> 1) & nl;                       // a = 1
+                    const uint32_t t2 = ~(x >> 1) & nl;                      // a = 2
+                    n1[q] += __popc(t1);
+                    n2[q] += __popc(t2);
+                    f[d] = t1 | (t2 << 1);                                   // the 2-bit field now holds a
+                }
+                const as_v4i a0 = {(int)(f[0] & M0), (int)(f[1] & M0), (int)(f[2] & M0), (int)(f[3] & M0)};
+                const as_v4i a1 = {(int)(f[0] & (M0 << 2)), (int)(f[1] & (M0 << 2)), (int)(f[2] & (M0 << 2)), (int)(f[3] & (M0 << 2))};
+                const as_v4i a2 = {(int)(f[0] & (M0 << 4)), (int)(f[1] & (M0 << 4)), (int)(f[2] & (M0 << 4)), (int)(f[3] & (M0 << 4))};
+                const as_v4i a3 = {(int)((f[0] >> 6) & M0), (int)((f[1] >> 6) & M0), (int)((f[2] >> 6) & M0), (int)((f[3] >> 6) & M0)};
+                acc0[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc0[q], 0, 0, 0);
+                acc1[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc1[q], 0, 0, 0);
+                acc2[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc2[q], 0, 0, 0);
+                acc0[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, b3, acc0[q], 0, 0, 0);
+            }
+            if (blk + 1 < nblk) request(blk + 1, s);
+        }
+        if (blk + 1 < nblk) {
+#pragma unroll
+            for (int n = 0; n < 8; n++) *reinterpret_cast<uint2*>(s_pl[par ^ 1] + n * AS_PST + (n >> 2) * 64 + 8 * tid) = pb[n];
+        }
+    }
+    // C: column n = lane & 15 (digit plane n < 8), rows 4 kg + r (marker of the tile); the four planes of a part meet in a quad
+    const int n = lane & 15;
+    const int sh = assoc_shift(*maxbits);
+    const bool nonfinite = ((*maxbits >> 52) & 0x7ffull) == 0x7ffull;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        // every lane (mrow, kg) counted its own marker over its chunks: the four kg lanes of a marker row add up
+        int c1 = n1[q], c2 = n2[q];
+        c1 += __shfl_xor(c1, 16, 64); c1 += __shfl_xor(c1, 32, 64);
+        c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
+        const int mq = mbase + 16 * q + mrow;
+        if (kg == 0 && mq < M) xtx[mq] = (double)((long long)c1 + 4ll * (long long)c2);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int x = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);
+            long long sx = (long long)x << (8 * (n & 3));
+            sx += ((long long)__shfl_xor((int)(sx >> 32), 1, 64) << 32) + (long long)(unsigned)__shfl_xor((int)sx, 1, 64);
+            sx += ((long long)__shfl_xor((int)(sx >> 32), 2, 64) << 32) + (long long)(unsigned)__shfl_xor((int)sx, 2, 64);
+            // lanes n = 0..3 hold the sum of part 1 (units of 2^-22), n = 4..7 of part 2 (units of 2^-53)
+            const long long s2 = ((long long)__shfl((int)(sx >> 32), (lane & 48) + 4, 64) << 32) | (long long)(unsigned)__shfl((int)sx, (lane & 48) + 4, 64);
+            const int mr = mbase + 16 * q + 4 * kg + r;
+            if (n == 0 && mr < M)
+                xty[mr] = nonfinite ? __longlong_as_double(0x7ff8000000000000ll)   // a NaN or Inf in y: no digits to sum
+                                    : __builtin_ldexp((double)sx * 0x1p-22 + (double)s2 * 0x1p-53, -sh);
+        }
     }
 }
 
@@ -444,10 +575,23 @@ hipError_t launch_predict_g(const uint8_t* bed, const uint8_t* namask2, size_t s
         hipLaunchKernelGGL(k_predict_g<1>, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, bed, namask2, stride, M, mave, msig, beta, g);
     return hipGetLastError();
 }
+size_t assoc_workspace_bytes(size_t stride) {
+    const size_t npad = (4 * stride + 4 * AS_BLK - 1) / (4 * AS_BLK) * (4 * AS_BLK);
+    return 8 * npad + 64;
+}
+// ws: assoc_workspace_bytes(stride) bytes of device memory (digit planes of y, the scale)
 hipError_t launch_assoc(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* y,
-                        double* xtx, double* xty, hipStream_t st) {
-    if (M <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_assoc, dim3((M + 4 * AB - 1) / (4 * AB)), dim3(256), 0, st, bed, namask2, stride, M, y, xtx, xty);
+                        double* xtx, double* xty, void* ws, hipStream_t st) {
+    if (M <= 0 || stride == 0) return hipSuccess;
+    const size_t npad = (4 * stride + 4 * AS_BLK - 1) / (4 * AS_BLK) * (4 * AS_BLK);
+    uint8_t* planes = static_cast<uint8_t*>(ws);
+    unsigned long long* maxbits = reinterpret_cast<unsigned long long*>(planes + 8 * npad);
+    hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, y, 4 * stride, maxbits);
+    hipLaunchKernelGGL(k_yplanes, dim3((unsigned)((npad / 4 + 255) / 256)), dim3(256), 0, st, y, namask2, stride, maxbits, planes, npad);
+    hipLaunchKernelGGL(k_assoc_mfma, dim3((unsigned)((M + AS_MB - 1) / AS_MB)), dim3(256), 0, st, bed, namask2, stride, M,
+                       planes, npad, maxbits, xtx, xty);
     return hipGetLastError();
 }
 

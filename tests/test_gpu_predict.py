@@ -49,6 +49,35 @@ def test_predict_g_and_assoc_match_the_reference_loops(gpu, name):
         ctx.close()
 
 
+@pytest.mark.parametrize("scale", [1.0, 3.7e9, 2.0 ** -40])
+def test_assoc_over_many_blocks_and_scales(gpu, scale):
+    """gmrm_assoc on the matrix cores (k_assoc_mfma): several 2048-individual blocks with a ragged tail, a marker count
+    that is no multiple of the 128 a workgroup takes, NAs and missing genotypes, phenotypes far from unit scale (the
+    kernel scales y by a power of two before cutting it into digit planes).  xtx is an integer, xty the exact sum
+    rounded once: within 1e-12 of the reference's left-to-right f64 sum.  predict_g on the same block, bit for bit."""
+    case = cases.Case("assoc", 21_003, 333, 2, 4, 1, 0.03, 700, 11, 1, 20)
+    inp = cases.make_inputs(case)
+    ctx, eps, mask4, nonas, mave, msig = _ctx_with_trait(case, inp)
+    try:
+        rng = np.random.default_rng(8)
+        yk = rng.normal(size=case.N) * scale
+        yk[rng.integers(0, case.N, 50)] *= 40.0                  # a few outliers set the scale
+        xtx, xty = ctx.assoc(0, yk)
+        wxx, wxy = orc.assoc(inp["bed"], mask4, yk)
+        assert np.array_equal(xtx, wxx)
+        assert np.allclose(xty, wxy, rtol=1e-12, atol=1e-12 * scale)
+        beta = rng.normal(0.0, 0.01, size=case.M)
+        g = ctx.predict_g(0, beta)
+        assert np.array_equal(g, orc.predict_g(inp["bed"], mask4, mave, msig, beta)[:case.N])
+        zero = ctx.assoc(0, np.zeros(case.N))[1]
+        assert not zero.any()
+        bad = yk.copy()
+        bad[5] = np.inf
+        assert np.isnan(ctx.assoc(0, bad)[1]).all()              # a non-finite phenotype is reported, not summed
+    finally:
+        ctx.close()
+
+
 def test_cli_predict_writes_the_reference_mlma_records(gpu, tmp_path):
     assert BIN.exists(), "bin/gmrm_hip not built (python __graft_entry__.py)"
     case = cases.CASE_BY_NAME["ragged"]
