@@ -329,28 +329,44 @@ __global__ __launch_bounds__(256) void k_predict_g(const uint8_t* __restrict__ b
     double acc[NI];
 #pragma unroll
     for (int i = 0; i < NI; i++) acc[i] = 0.0;
+    // Everything a chunk needs from global memory is requested one chunk ahead: its U column words and, for the
+    // 128 threads that build the value table, the effect and the statistics of their marker.
+    const int tu = threadIdx.x >> 2, tc = threadIdx.x & 3;          // table entry of this thread: (marker of the chunk, code)
+    const bool builder = threadIdx.x < U * 4;
+    uint32_t wn[U];
+    double nb_ = 0.0, nmv = 0.0, nms = 0.0;
+    auto request = [&](int m0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int m = m0 + u < M ? m0 + u : M - 1;
+            wn[u] = live ? reinterpret_cast<const word_t*>(bed + (size_t)m * stride)[w] : 0u;
+        }
+        if (builder) {
+            const int m = m0 + tu;
+            nb_ = m < M ? beta[m] : 0.0;
+            nmv = m < M ? mave[m] : 0.0;
+            nms = m < M ? msig[m] : 0.0;
+        }
+    };
+    request(0);
     int par = 0;
     for (int m0 = 0; m0 < M; m0 += U, par ^= 1) {
         uint32_t wd[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int m = m0 + u < M ? m0 + u : M - 1;
-            wd[u] = live ? reinterpret_cast<const word_t*>(bed + (size_t)m * stride)[w] : 0u;
-        }
-        if (threadIdx.x < U * 4) {                                  // one (marker, code) entry per thread
-            const int u = threadIdx.x >> 2, c = threadIdx.x & 3;
-            const int m = m0 + u;
-            const double bm = m < M ? beta[m] : 0.0;
+        for (int u = 0; u < U; u++) wd[u] = wn[u];
+        if (builder) {
             double tv = 0.0;
-            if (bm != 0.0) tv = (((code_a(c) - mave[m]) * code_b(c)) * msig[m]) * bm;
-            s_tv[par][u][c] = tv;
+            if (nb_ != 0.0) tv = (((code_a(tc) - nmv) * code_b(tc)) * nms) * nb_;
+            s_tv[par][tu][tc] = tv;
         }
+        if (m0 + U < M) request(m0 + U);
         __syncthreads();                                            // one barrier per chunk: the other parity is free by now
         // No test per marker: a marker with a zero effect (or behind the end of the block) adds +0.0, which leaves
         // an accumulator as it is (an accumulator is never -0.0: it starts at +0.0 and x + (-x) rounds to +0.0), and a
         // wave-uniform branch per marker would keep the scheduler from issuing the next marker's table reads
-        // under this one's additions -- the kernel is bound by exactly those LDS reads.  (A 16-entry table per
-        // marker that serves two individuals with one 16-byte read was measured: 0.82 TB/s against 1.08.)
+        // under this one's additions -- the kernel is bound by exactly those LDS reads.  (Measured and dropped: a
+        // 16-entry table per marker serving two individuals with one 16-byte read, 0.82 TB/s against 1.08; half a byte
+        // per thread, i.e. four wavefronts per SIMD instead of two, 1.06 against 1.28.)
         const char* tvb = reinterpret_cast<const char*>(&s_tv[par][0][0]);
 #pragma unroll
         for (int u = 0; u < U; u++) {
