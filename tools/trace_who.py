@@ -43,3 +43,17 @@ for k in (1, 2, 3, 5, 6):
         who[int(v.argmax())] += 1
     if lag:
         print(f'{names[k]:13s}: last - median = {np.mean(lag):5.2f} us on average; most often last: {who.most_common(6)}')
+
+# per-workgroup mean lag (own stamp - median of the round) at 'dots done' and 'totals seen'
+for k in (1, 3):
+    acc = np.zeros(W); cnt = 0
+    for r in range(64):
+        v = t[:, r, k]
+        if (v == 0).all() or (t[:, r, 5] == 0).all():
+            continue
+        acc += v - np.median(v); cnt += 1
+    if cnt:
+        m = acc / cnt
+        order = np.argsort(-m)
+        print(f'{names[k]:13s}: mean lag per workgroup, slowest 40:', ' '.join(f'{int(w)}:{m[w]:.2f}' for w in order[:40]))
+        print(f'{"":13s}  fastest 10:', ' '.join(f'{int(w)}:{m[w]:.2f}' for w in order[-10:]))
