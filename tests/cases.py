@@ -202,6 +202,19 @@ def write_golden(gold_dir):
         print(case.name, "written; updates per sweep:", [int(x) for x in canon[0]["nupd"]])
 
 
+def write_golden_shards(gold_dir):
+    """shards_k3_3ranks.npz: case k3 on 3 ranks, 4 iterations, under both multi-rank schedules of the oracle."""
+    case = CASE_BY_NAME["k3"]
+    inp = make_inputs(case)
+    out = {}
+    for sched in ("sweep", "steps"):
+        h = run_oracle(case, inp, iters=4, canon=True, nranks=3, schedule=sched)[0]
+        out[f"{sched}_comp"] = np.array(h["comp"], dtype=np.int8)
+        out[f"{sched}_betas"] = np.array(h["betas"])
+        out[f"{sched}_csv"] = np.frombuffer(b"".join(h["csv"]), dtype=np.uint8)
+    np.savez_compressed(Path(gold_dir) / "shards_k3_3ranks.npz", **out)
+
+
 def load_golden(name):
     z = np.load(golden_path(name))
     inp = dict(bed=z["bed"], y=z["y"], isna=z["isna"], group_index=z["group_index"], cva=z["cva"])

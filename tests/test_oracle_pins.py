@@ -244,6 +244,21 @@ def test_per_step_schedule_of_the_reference():
     assert 0.1 < ps[0]["sigmae"][-1] < 2.0
 
 
+def test_multi_rank_schedules_reproduce_their_fixture():
+    """tests/golden/shards_k3_3ranks.npz: 4 iterations of case k3 on 3 ranks under the two multi-rank schedules
+    (orc_ns_iterate: one exchange per sweep; orc_ps_iterate: the reference's exchange per marker step).  Written by
+    this oracle (the reference's MPI build cannot run here): a regression pin for both restatements, which the GPU
+    tests then hold the product to."""
+    z = np.load(GOLD / "shards_k3_3ranks.npz")
+    case = cases.CASE_BY_NAME["k3"]
+    inp, _ = cases.load_golden("k3")
+    for sched in ("sweep", "steps"):
+        h = cases.run_oracle(case, inp, iters=4, canon=True, nranks=3, schedule=sched)[0]
+        assert np.array_equal(np.array(h["comp"], dtype=np.int8), z[f"{sched}_comp"]), sched
+        assert np.array_equal(np.array(h["betas"]), z[f"{sched}_betas"]), sched
+        assert b"".join(h["csv"]) == z[f"{sched}_csv"].tobytes(), sched
+
+
 def test_predict_restatement_against_numpy():
     """Bayes::predict's loops (bayes.cpp:93-122, 172-205, 233-234) as restated in the oracle, checked
     against a direct numpy evaluation of the same formulas on decoded genotypes (no GPU)."""

@@ -9,6 +9,8 @@
   chain_*.npz          seeded small-case inputs + the oracle's outputs (both summation
                        modes), so the GPU box can check the oracle it rebuilt and the HIP
                        path against committed numbers.
+  shards_k3_3ranks.npz case k3 on 3 ranks under the oracle's two multi-rank schedules (one exchange per sweep;
+                       the reference's exchange per marker step).
 Fixtures are data only: no reference source text is stored.
 """
 import os
@@ -55,6 +57,7 @@ def ref_parts():
 def chain_parts():
     from tests import cases
     cases.write_golden(GOLD)
+    cases.write_golden_shards(GOLD)
 
 
 if __name__ == "__main__":
