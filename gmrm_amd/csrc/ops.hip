@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void k_predict_g(const uint8_t* __restrict__ b
 // real number than the reference's left-to-right f64 sum (tests: 1e-12 relative).  xtx (= #(a=1) + 4 #(a=2)) comes
 // from two popcounts per dword.  The genotype columns are read once, 16 bytes per lane; the planes of a 2048-individual
 // block are staged in LDS for the four wavefronts (32 markers each) of a workgroup.
-constexpr int AS_BLK = 512;                       // column bytes per block
+constexpr int AS_BLK = 512;                       // column bytes per block (256: two wavefronts per SIMD at 200 VGPRs, same speed)
 constexpr int AS_SS = AS_BLK / 64;                // super-steps (256 individuals) per block
 constexpr int AS_PST = 4 * AS_BLK + 16;           // LDS bytes per plane: the offsets of sweep.hip's Geo<R>::PSTRIDE (bank spreading)
 constexpr int AS_PLN = 8 * AS_PST + 64;
@@ -452,6 +452,7 @@ __global__ __launch_bounds__(256) void k_assoc_mfma(const uint8_t* __restrict__ 
                                                     const unsigned long long* __restrict__ maxbits,
                                                     double* __restrict__ xtx, double* __restrict__ xty) {
     __shared__ __attribute__((aligned(16))) char s_pl[2][AS_PLN];
+    __shared__ __attribute__((aligned(16))) uint4 s_nm[2][AS_BLK / 16];   // the block's NA mask, staged with the planes
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int mrow = lane & 15, kg = lane >> 4;
     const int mbase = blockIdx.x * AS_MB + wave * AS_MW;
@@ -464,11 +465,19 @@ __global__ __launch_bounds__(256) void k_assoc_mfma(const uint8_t* __restrict__ 
     const size_t nchunk = stride / 16;                               // the column stride is a multiple of 16
     const int nblk = (int)((stride + AS_BLK - 1) / AS_BLK);
     // the planes of block 0 -> LDS buffer 0 (thread t: 8 bytes of every plane)
-    uint2 pb[8];
+    typedef typename std::conditional<AS_BLK == 512, uint2, uint32_t>::type pbt;   // 4 * AS_BLK / 256 bytes per thread and plane
+    constexpr int PBB = (int)sizeof(pbt);
+    pbt pb[8];
 #pragma unroll
-    for (int n = 0; n < 8; n++) pb[n] = *reinterpret_cast<const uint2*>(planes + (size_t)n * npad + 8 * (size_t)tid);
+    for (int n = 0; n < 8; n++) pb[n] = *reinterpret_cast<const pbt*>(planes + (size_t)n * npad + PBB * (size_t)tid);
 #pragma unroll
-    for (int n = 0; n < 8; n++) *reinterpret_cast<uint2*>(s_pl[0] + n * AS_PST + (n >> 2) * 64 + 8 * tid) = pb[n];
+    for (int n = 0; n < 8; n++) *reinterpret_cast<pbt*>(s_pl[0] + n * AS_PST + (n >> 2) * 64 + PBB * tid) = pb[n];
+    auto nam_chunk = [&](int blk) -> uint4 {                          // thread tid < 32: chunk tid of the block's mask
+        const size_t ci = (size_t)blk * (AS_BLK / 16) + (size_t)tid;
+        return (tid < AS_BLK / 16 && ci < nchunk) ? *reinterpret_cast<const uint4*>(namask2 + 16 * ci) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    uint4 pn = nam_chunk(0);
+    if (tid < AS_BLK / 16) s_nm[0][tid] = pn;
     as_v4i acc0[2], acc1[2], acc2[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) { acc0[q] = as_v4i{0, 0, 0, 0}; acc1[q] = as_v4i{0, 0, 0, 0}; acc2[q] = as_v4i{0, 0, 0, 0}; }
@@ -476,11 +485,10 @@ __global__ __launch_bounds__(256) void k_assoc_mfma(const uint8_t* __restrict__ 
     constexpr uint32_t M0 = 0x03030303u, LO = 0x55555555u;
     // a rolling window of AS_SS super-steps of column chunks: a chunk is requested again (for the next block) as soon
     // as it has been used, so that a block's worth of loads is always in flight
-    uint4 wa[AS_SS][2], wn[AS_SS];
+    uint4 wa[AS_SS][2];
     auto request = [&](int blk, int s) {
         const size_t ci = (size_t)blk * (AS_BLK / 16) + 4 * (size_t)s + (size_t)kg;
         const bool in = ci < nchunk;
-        wn[s] = in ? *reinterpret_cast<const uint4*>(namask2 + 16 * ci) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
         for (int q = 0; q < 2; q++) wa[s][q] = in ? *reinterpret_cast<const uint4*>(col[q] + 16 * ci) : make_uint4(0u, 0u, 0u, 0u);
     };
@@ -492,7 +500,8 @@ __global__ __launch_bounds__(256) void k_assoc_mfma(const uint8_t* __restrict__ 
         if (blk + 1 < nblk) {
 #pragma unroll
             for (int n = 0; n < 8; n++)
-                pb[n] = *reinterpret_cast<const uint2*>(planes + (size_t)n * npad + (size_t)(blk + 1) * 4 * AS_BLK + 8 * (size_t)tid);
+                pb[n] = *reinterpret_cast<const pbt*>(planes + (size_t)n * npad + (size_t)(blk + 1) * 4 * AS_BLK + PBB * (size_t)tid);
+            pn = nam_chunk(blk + 1);
         }
         const char* pbase = s_pl[par] + (lane & 7) * AS_PST + ((lane & 7) >> 2) * 64 + kg * 64;
 #pragma unroll
@@ -501,7 +510,8 @@ __global__ __launch_bounds__(256) void k_assoc_mfma(const uint8_t* __restrict__ 
             const as_v4i b1 = *reinterpret_cast<const as_v4i*>(pbase + s * 256 + 16);
             const as_v4i b2 = *reinterpret_cast<const as_v4i*>(pbase + s * 256 + 32);
             const as_v4i b3 = *reinterpret_cast<const as_v4i*>(pbase + s * 256 + 48);
-            const uint32_t nm[4] = {wn[s].x, wn[s].y, wn[s].z, wn[s].w};
+            const uint4 wn = s_nm[par][4 * s + kg];
+            const uint32_t nm[4] = {wn.x, wn.y, wn.z, wn.w};
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const uint32_t w4[4] = {wa[s][q].x, wa[s][q].y, wa[s][q].z, wa[s][q].w};
@@ -529,7 +539,8 @@ __global__ __launch_bounds__(256) void k_assoc_mfma(const uint8_t* __restrict__ 
         }
         if (blk + 1 < nblk) {
 #pragma unroll
-            for (int n = 0; n < 8; n++) *reinterpret_cast<uint2*>(s_pl[par ^ 1] + n * AS_PST + (n >> 2) * 64 + 8 * tid) = pb[n];
+            for (int n = 0; n < 8; n++) *reinterpret_cast<pbt*>(s_pl[par ^ 1] + n * AS_PST + (n >> 2) * 64 + PBB * tid) = pb[n];
+            if (tid < AS_BLK / 16) s_nm[par ^ 1][tid] = pn;
         }
     }
     // C: column n = lane & 15 (digit plane n < 8), rows 4 kg + r (marker of the tile); the four planes of a part meet in a quad
