@@ -129,6 +129,60 @@ def test_c4_four_traits_at_full_width_run_as_queued_pairs(gpu):
     ctx.close()
 
 
+@pytest.mark.parametrize("name,na_rate,miss_rate,G,dirty", [("c3", 0.002, 0.0, 1, 0.0), ("c5", 0.05, 0.05, 24, 0.0),
+                                                           ("mixed", 0.0, 0.001, 1, 0.005)])
+def test_full_size_chain_keeps_its_invariant(gpu, name, na_rate, miss_rate, G, dirty):
+    """BASELINE configs 3 and 5 (5 % NAs, 5 % missing genotypes, 24 groups: the 4-value exchange layout), and a block
+    with missing calls in 0.5 % of the markers only (the per-marker layout with its sparse missing-genotype terms), at FULL size (500 000 individuals x 1 000 000 markers, device-generated genotypes, 125 GB):
+    no oracle can sweep this in test time, so the chain is held to the property that defines it.  After k sweeps the
+    residual must be  y_std - mu - sum_m beta_m z_m  for the effects the sweeps left behind, with z the standardised
+    genotype columns: recomputed here from the kernel's own outputs with gmrm_predict_g (an independent kernel that
+    adds the markers in order).  Every residual update of three sweeps (~140 000 columns of 125 KB) has to be right
+    for this to hold to 1e-9; the bookkeeping (component counts, markers in the model, batches) is checked beside it."""
+    N, M = 500_000, 1_000_000
+    rng = np.random.default_rng(2)
+    y = rng.normal(size=N)
+    isna = (rng.random(N) < na_rate).astype(np.uint8)
+    eps0, mask4, nonas = orc.phen_prepare(y, isna)
+    ctx = gmrm_amd.Context(N, M)
+    try:
+        ctx.synth_bed(171014, 0.4, 0.0 if dirty else miss_rate)
+        if dirty:                                                    # code 01 (missing) in `miss_rate` of the calls of a few markers
+            nd, per = int(M * dirty), int(N * miss_rate)
+            cols = ctx.download_bed(0, nd)
+            who = rng.integers(0, N, size=(nd, per))
+            rows = np.repeat(np.arange(nd), per)
+            byte, sh = (who // 4).ravel(), (2 * (who % 4)).ravel().astype(np.uint8)
+            cols[rows, byte] = (cols[rows, byte] & ~(np.uint8(3) << sh)) | (np.uint8(1) << sh)
+            ctx.upload_bed(cols, 0)
+            del cols, who, rows, byte, sh
+        ctx.upload_trait(0, eps0, mask4, nonas)
+        ctx.compute_markers_statistics(0)
+        cva = np.tile(np.array([[0.0, 0.0001, 0.001, 0.01]]), (G, 1)) * np.linspace(1.0, 2.0, G)[:, None]
+        smp = gmrm_amd.Sampler(ctx, 171014, cva, rng.integers(0, G, M).astype(np.int32))
+        keep = np.repeat(mask4, 4) >> np.tile(np.arange(4), len(mask4)) & 1        # 1 = phenotype present
+        total_updates = 0
+        for it in (1, 2, 3):
+            smp.iterate(it)
+            hy = smp.hyper(0)
+            total_updates += hy.n_updates
+            comp, betas = ctx.comp(0), ctx.betas(0)
+            counts = np.bincount(comp, minlength=4)
+            assert counts.sum() == M and int((betas != 0.0).sum()) == M - counts[0] == hy.m0_sum, name
+            assert hy.n_batches >= hy.n_updates and 0.1 < hy.sigmae < 2.0
+            if dirty:
+                assert 0 < hy.n_fast_batches < hy.n_batches                      # clean and mixed batches both occur
+            g = ctx.predict_g(0, betas)
+            want = (eps0[:N] - hy.mu - g) * keep[:N]
+            got = ctx.get_epsilon(0)[:N]
+            assert np.max(np.abs(got - want)) < 1e-9, (it, float(np.max(np.abs(got - want))))
+            assert not got[keep[:N] == 0].any()                                    # NA individuals stay out of the residual
+        assert total_updates > 100_000
+        smp.close()
+    finally:
+        ctx.close()
+
+
 def test_largest_supported_width_one_workgroup_per_compute_unit(gpu):
     """The widest geometry: N = 256 workgroups x 256 threads x 4 bytes x 4 individuals = 1 048 576 (R = 4, one
     workgroup on every compute unit), and one more individual is refused with the limit in the message."""
