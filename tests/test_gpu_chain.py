@@ -353,3 +353,59 @@ def test_per_step_calls_and_the_sweep_kernel_are_one_chain(gpu):
             assert smp.csv_line(t, it) == c.csv_line(it)
     with pytest.raises(gmrm_amd.GmrmError):
         smp.step(0)                                          # outside begin_steps .. end_steps
+
+
+def _rccl_one_rank_worker(_index, port, out_path):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    from gmrm_amd.dist import HipEngine
+    case = cases.CASE_BY_NAME["ragged"]
+    inp = cases.make_inputs(case)
+    eps, mask4, nonas = cases.prepare_traits(inp)[0]
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", device_id=dev)
+    ctx = gmrm_amd.Context(case.N, case.M, T=1)
+    ctx.upload_bed(inp["bed"])
+    ctx.upload_trait(0, eps, mask4, nonas)
+    mave, msig = ctx.compute_markers_statistics(0)
+    smp = gmrm_amd.Sampler(ctx, case.seed, inp["cva"], inp["group_index"])
+    eng = HipEngine(smp, dev)                                   # device tensors straight into the collective
+    ctx.eps_snapshot(0)
+    start = ctx.get_epsilon(0)
+    for m in (3, 17, 40):
+        ctx.update_epsilon([0.01 * (m + 1), mave[m], msig[m]], m, 0)
+    moved = ctx.get_epsilon(0)
+    q = eng.delta_export(0)                                     # written by this library into torch's memory
+    assert q.is_cuda
+    q_host = q.cpu().numpy().copy()                             # the two exact parts of (residual - snapshot)
+    dist.all_reduce(q, op=dist.ReduceOp.SUM)                    # RCCL, one rank: must hand the same bits back
+    unchanged = np.array_equal(q.cpu().numpy(), q_host)
+    eng.delta_import(0, q)
+    got = ctx.get_epsilon(0)
+    n4 = len(start)
+    want = start + (q_host[:n4] + q_host[n4:])                  # k_delta_import's expression on the host
+    parts_ok = np.max(np.abs((q_host[:n4] + q_host[n4:]) - (moved - start))) < 2.0 ** -52
+    np.savez(out_path, same=np.array_equal(got, want), moved=not np.array_equal(moved, start), unchanged=unchanged, parts_ok=parts_ok)
+    smp.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def test_residual_exchange_through_torch_memory_and_rccl(gpu, tmp_path):
+    """What `bench.py --gpus N` does between sweeps, with the one rank a one-GPU box allows: the library writes the
+    exact residual delta into a TORCH tensor on the device, torch.distributed (backend nccl = RCCL) all-reduces it in
+    place, the library reads it back: the parts must survive the collective bit for bit and the residual must be
+    snapshot + (part 1 + part 2) -- this is the path where two HIP runtimes in one process, a wrong stream or a
+    host copy would show."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "r.npz"
+    mp.spawn(_rccl_one_rank_worker, args=(port, str(out)), nprocs=1, join=True)
+    z = np.load(out)
+    assert bool(z["moved"]) and bool(z["parts_ok"]) and bool(z["unchanged"]) and bool(z["same"])
