@@ -1359,7 +1359,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (wg < b.nv) {
             const unsigned long long* Pb = Pg + 2 * (size_t)(b.gen & 1u) * SW_VMAX * a.Wpad;
             unsigned long long* Tb = Ttg + 2 * (size_t)(b.gen & 1u) * SW_VMAX;
-            for (int v = wg; v < b.nv; v += W) {
+            const int rows = (b.nv - wg + W - 1) / W;         // rows wg, wg + W, ... of this workgroup (uniform)
+            if (rows == 1) {
+                const int v = wg;
                 double x = 0.0;
                 if (tid < W) {
                     Spin sp;
@@ -1374,6 +1376,29 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 if (lane == 0) s_red[wave] = x;
                 lds_barrier();
                 if (tid == 0) put_value(Tb + 2 * v, b.gen + 1u, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+                lds_barrier();
+            } else {
+                // Fewer workgroups than rows (small N: 49 workgroups, up to 242 rows): all rows of this workgroup in ONE
+                // pass -- thread t waits for granules t, t + 256, ... of the rows x W it needs and adds each to its row's
+                // LDS accumulator (ds_add_f64; the values are exact, so the order does not matter).  One row after the
+                // other cost a memory round trip and two barriers per row.
+                double* s_rows = reinterpret_cast<double*>(smem + L_TOT);       // free until wavefront 0 polls the totals
+                if (tid < rows) s_rows[tid] = 0.0;
+                lds_barrier();
+                const int total = rows * W;
+                for (int g = tid; g < total; g += SW_TPB) {
+                    const int r = g / W, i = g - r * W;
+                    Spin sp;
+                    sp.start(spin_limit);
+                    double x = 0.0;
+                    const unsigned long long* gp = Pb + 2 * ((size_t)(wg + r * W) * a.Wpad + i);
+                    while (!get_value(gp, b.gen + 1u, x)) {
+                        if (sp.expired(abort_word)) { bad = true; x = 0.0; break; }
+                    }
+                    __hip_atomic_fetch_add(&s_rows[r], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                lds_barrier();
+                if (tid < rows) put_value(Tb + 2 * (wg + tid * W), b.gen + 1u, s_rows[tid]);
                 lds_barrier();
             }
         }
