@@ -295,7 +295,11 @@ int gmrm_upload_trait(gmrm_ctx* c, int t, const double* eps, const uint8_t* mask
     }
     HIPCHK(hipMemcpy(tr.namask2, m2.data(), c->stride, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(tr.eps, 0, 4 * c->stride * sizeof(double)));
-    HIPCHK(hipMemcpy(tr.eps, eps, 4 * c->mbytes * sizeof(double), hipMemcpyHostToDevice));
+    {   // the residual lives on the grid 2^-44 (gm_common.h): rounded here, exact from then on
+        std::vector<double> q(4 * c->mbytes);
+        for (size_t i = 0; i < q.size(); i++) q[i] = gm::grid(eps[i]);
+        HIPCHK(hipMemcpy(tr.eps, q.data(), q.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     tr.nonas = nonas;
     tr.have_trait = true;
     tr.have_stats = false;
@@ -317,7 +321,9 @@ int gmrm_upload_eps(gmrm_ctx* c, int t, const double* eps) {
     if (!eps) return fail(GMRM_EINVAL, "null argument");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->tr[t].stream));
-    HIPCHK(hipMemcpy(c->tr[t].eps, eps, 4 * c->mbytes * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> q(4 * c->mbytes);                      // values read back from this library are on the grid already
+    for (size_t i = 0; i < q.size(); i++) q[i] = gm::grid(eps[i]);
+    HIPCHK(hipMemcpy(c->tr[t].eps, q.data(), q.size() * sizeof(double), hipMemcpyHostToDevice));
     return GMRM_OK;
 }
 
@@ -388,12 +394,9 @@ int gmrm_update_eps(gmrm_ctx* c, int t, int mloc, const double* dbeta) {
     if (mloc < 0 || mloc >= c->M || !dbeta) return fail(GMRM_EINVAL, "marker index out of range");
     HIPCHK(hipSetDevice(c->device));
     Trait& tr = c->tr[t];
-    const double bs_ = dbeta[0] * dbeta[2];                    // phenotype.cpp:328-329
-    const double mdb = -dbeta[1];
-    const double v0 = (mdb * 1.0 + 2.0) * bs_;                 // phenotype.cpp:385-388 per 2-bit code
-    const double v1 = (mdb * 0.0 + 0.0) * bs_;
-    const double v2 = (mdb * 1.0 + 1.0) * bs_;
-    const double v3 = (mdb * 1.0 + 0.0) * bs_;
+    double alpha_, beta_;                                      // phenotype.cpp:328-329,385-388 on the residual's grid
+    gm::update_values(dbeta[0], dbeta[1], dbeta[2], alpha_, beta_);
+    const double v3 = beta_, v2 = beta_ + alpha_, v0 = v2 + alpha_, v1 = 0.0;   // per .bed code: a = 0, 1, 2, missing
     HIPCHK(launch_update(tr.eps, c->bed + (size_t)mloc * c->stride, tr.namask2, c->stride, v0, v1, v2, v3, tr.stream));
     HIPCHK(hipStreamSynchronize(tr.stream));
     return GMRM_OK;
@@ -417,12 +420,9 @@ int gmrm_update_eps_from(gmrm_ctx* c, int t, gmrm_ctx* src, int mloc, const doub
         HIPCHK(hipMemcpyPeerAsync(c->colbuf, c->device, col, src->device, c->stride, tr.stream));
         col = c->colbuf;
     }
-    const double bs_ = dbeta[0] * dbeta[2];                    // phenotype.cpp:328-329
-    const double mdb = -dbeta[1];
-    const double v0 = (mdb * 1.0 + 2.0) * bs_;                 // phenotype.cpp:385-388 per 2-bit code
-    const double v1 = (mdb * 0.0 + 0.0) * bs_;
-    const double v2 = (mdb * 1.0 + 1.0) * bs_;
-    const double v3 = (mdb * 1.0 + 0.0) * bs_;
+    double alpha_, beta_;                                      // phenotype.cpp:328-329,385-388 on the residual's grid
+    gm::update_values(dbeta[0], dbeta[1], dbeta[2], alpha_, beta_);
+    const double v3 = beta_, v2 = beta_ + alpha_, v0 = v2 + alpha_, v1 = 0.0;   // per .bed code: a = 0, 1, 2, missing
     HIPCHK(launch_update(tr.eps, col, tr.namask2, c->stride, v0, v1, v2, v3, tr.stream));
     HIPCHK(hipStreamSynchronize(tr.stream));
     return GMRM_OK;
@@ -432,7 +432,7 @@ int gmrm_offset_eps(gmrm_ctx* c, int t, double offset) {
     if (int r = need_trait(c, t, false)) return r;
     HIPCHK(hipSetDevice(c->device));
     Trait& tr = c->tr[t];
-    HIPCHK(launch_offset(tr.eps, tr.namask2, c->stride, offset, tr.stream));
+    HIPCHK(launch_offset(tr.eps, tr.namask2, c->stride, gm::grid(offset), tr.stream));      // the residual stays on its grid
     HIPCHK(hipStreamSynchronize(tr.stream));
     return GMRM_OK;
 }

@@ -51,6 +51,26 @@ GM_HD void split2sq(double x, double& q1, double& q2) {
     q2 = u - SPLIT_S2;
 }
 
+// ---- the fixed-point residual ----------------------------------------------------------
+// The residual lives on the grid 2^-44: every value is k * 2^-44 with |k| < 2^52 (|eps| < 2^8), an exactly
+// representable double, and every update ADDS a grid value -- eps + v is exact, no rounding per individual --
+// so that a dot product after an update equals the dot product before it plus an integer-linear correction:
+// the sweep kernel walks past a marker whose effect changes without recomputing the dots behind it
+// (sweep.hip, "continuation").  The update values of one marker are linear in the genotype value a:
+//   v(a) = beta_ + a * alpha_,   alpha_ = grid(bs_),  beta_ = grid(mdb * bs_)
+// with bs_ = dbeta * msig and mdb = -mave of phenotype.cpp:328-329; the reference evaluates
+// fl(fl(mdb * b + a) * bs_), the same real number to ~1 ulp (|difference| <= 2^-44 per individual and update).
+constexpr double GRID     = 0x1p-44;
+constexpr double GRID_INV = 0x1p+44;
+GM_HD double grid(double x) { return __builtin_rint(x * GRID_INV) * GRID; }   // nearest multiple, ties to even (v_rndne_f64 / rint)
+// v[c] for the four .bed codes c (00: a = 2, 01: missing, 10: a = 1, 11: a = 0), from {dbeta, mave, msig}
+GM_HD void update_values(double dbeta, double mave, double msig, double& alpha_, double& beta_) {
+    const double bs_ = dbeta * msig;             // phenotype.cpp:328
+    const double mdb = -mave;                    // phenotype.cpp:329
+    alpha_ = grid(bs_);
+    beta_ = grid(mdb * bs_);
+}
+
 GM_HD double fma_(double a, double b, double c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_fma(a, b, c);

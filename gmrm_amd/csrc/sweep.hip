@@ -529,14 +529,15 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
             int upd = 0;
             if (fabs(dbeta) > 0.0) {                                     // bayes.cpp:483, phenotype.cpp:328-329,388
                 upd = 1;
-                const double bs_ = dbeta * in.msig;
-                const double mdb = -in.mave;
-                // (mdb * b + a) * bs_ per genotype, indexed by the RING code c' (k_sweep, phase A): c' = 2, 3, 1, 0
-                // for .bed codes 00, 01, 10, 11 with (a, b) = (2,1), (0,0), (1,1), (0,1) (src/dotp_lut.hpp)
-                s_val[2] = (mdb * 1.0 + 2.0) * bs_;
-                s_val[3] = (mdb * 0.0 + 0.0) * bs_;
-                s_val[1] = (mdb * 1.0 + 1.0) * bs_;
-                s_val[0] = (mdb * 1.0 + 0.0) * bs_;
+                // (mdb * b + a) * bs_ per genotype on the residual's grid (gm_common.h: v(a) = beta_ + a * alpha_), indexed
+                // by the RING code c' (k_sweep, phase A): c' = a for a = 0, 1, 2 and 3 for a missing genotype
+                double alpha_, beta_;
+                update_values(dbeta, in.mave, in.msig, alpha_, beta_);
+                const double v1 = beta_ + alpha_;
+                s_val[0] = beta_;
+                s_val[1] = v1;
+                s_val[2] = v1 + alpha_;
+                s_val[3] = 0.0;
             }
             if (writer) {
                 out.acum[m] = acum_v; out.betas_out[m] = beta_new; out.comp[m] = kc;

@@ -214,6 +214,46 @@ double orc_epsilon_sigma_canon(const double* epsilon, const uint8_t* mask4, int 
     return (s1 + s2) / (double)nonas * 0.5;
 }
 
+/* ---- the fixed-point residual of the canon mode -------------------------------------------
+ * In canon mode the residual lives on the grid 2^-44: every value is k * 2^-44 with |k| < 2^52
+ * (|eps| < 2^8), i.e. an exactly representable double, and every update ADDS a grid value, so
+ * eps + v is exact (no rounding per individual) and a dot product after an update equals the dot
+ * product before it plus an integer-linear correction.  That is what lets the HIP sweep kernel walk
+ * past a marker whose effect changes without recomputing the dots behind it (DESIGN.md 5.1,
+ * "continuation"); the ref mode keeps the reference's plain f64 update (phenotype.cpp:375-390).
+ * The update values of one marker are LINEAR in the genotype value a: v(a) = beta_ + a * alpha_ with
+ *   alpha_ = grid(bs_)          bs_ = dbeta * msig                    (phenotype.cpp:328)
+ *   beta_  = grid(mdb * bs_)    mdb = -mave                           (phenotype.cpp:329)
+ * against the reference's fl(fl(mdb * b + a) * bs_): the same real number to ~1 ulp, then the grid
+ * (|error| <= 2^-44 per individual and update, nine orders of magnitude inside the 1e-6 bar). */
+#define ORC_GRID     0x1p-44
+#define ORC_GRID_INV 0x1p+44
+double orc_grid(double x) { return rint(x * ORC_GRID_INV) * ORC_GRID; }
+void orc_grid_array(double* x, int n) { for (int i = 0; i < n; i++) x[i] = orc_grid(x[i]); }
+
+void orc_update_epsilon_canon(double* epsilon, const double* dbeta, const uint8_t* bed,
+                              const uint8_t* mask4, int im4) {
+    const double bs_ = dbeta[0] * dbeta[2];
+    const double mdb = -dbeta[1];
+    const double alpha_ = orc_grid(bs_);
+    const double beta_ = orc_grid(mdb * bs_);
+    const double v1 = beta_ + alpha_, v2 = v1 + alpha_;      /* exact while in range */
+    for (int i = 0; i < im4; i++)
+        for (int j = 0; j < 4; j++) {
+            if (!((mask4[i] >> j) & 1)) continue;            /* na_lut == 0 */
+            const int c = (bed[i] >> (2 * j)) & 3;
+            if (c == 1) continue;                            /* missing genotype: a = b = 0 */
+            epsilon[i * 4 + j] += (c == 0) ? v2 : (c == 2) ? v1 : beta_;
+        }
+}
+
+void orc_offset_epsilon_canon(double* epsilon, double offset, const uint8_t* mask4, int im4) {
+    const double off = orc_grid(offset);
+    for (int i = 0; i < im4; i++)
+        for (int j = 0; j < 4; j++)
+            if ((mask4[i] >> j) & 1) epsilon[i * 4 + j] += off;
+}
+
 /* genotype-code counts among non-NA individuals: cnt[c], c = 2-bit code */
 void orc_marker_counts(const uint8_t* bedm, int mbytes, const uint8_t* mask4, int64_t cnt[4]) {
     cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
@@ -518,6 +558,7 @@ orc_chain* orc_chain_create(int N, int M, int Mt, int S, int G, int K,
     c->bed = bed_local;
     c->eps = (double*)malloc(sizeof(double) * 4 * (size_t)c->im4);
     memcpy(c->eps, eps0, sizeof(double) * 4 * (size_t)c->im4);
+    if (canon) orc_grid_array(c->eps, 4 * c->im4);            /* the canon residual lives on the 2^-44 grid */
     c->mask4 = (uint8_t*)malloc((size_t)c->im4);
     memcpy(c->mask4, mask4, (size_t)c->im4);
     c->mave = (double*)calloc((size_t)M, sizeof(double));
@@ -583,10 +624,18 @@ static double chain_dot(orc_chain* c, int mloc) {
                     : orc_dot_product(col, c->eps, (int)c->mbytes, c->mave[mloc], c->msig[mloc]);
 }
 static double chain_exp(const orc_chain* c, double x) { return c->canon ? orc_exp(x) : exp(x); }
+static void chain_offset(orc_chain* c, double off) {
+    if (c->canon) orc_offset_epsilon_canon(c->eps, off, c->mask4, c->im4);
+    else          orc_offset_epsilon(c->eps, off, c->mask4, c->im4);
+}
+static void chain_update(orc_chain* dst, const double* d3, const uint8_t* col) {
+    if (dst->canon) orc_update_epsilon_canon(dst->eps, d3, col, dst->mask4, dst->im4);
+    else            orc_update_epsilon(dst->eps, d3, col, dst->mask4, dst->im4);
+}
 
 /* bayes.cpp:348-358: add the old mu back, (it==1) initial sigmae, draw the new mu */
 double orc_chain_prologue_draw(orc_chain* c, int it) {
-    orc_offset_epsilon(c->eps, c->mu, c->mask4, c->im4);
+    chain_offset(c, c->mu);
     if (it == 1)
         c->sigmae = c->canon ? orc_epsilon_sigma_canon(c->eps, c->mask4, c->im4, c->nonas)
                              : orc_epsilon_sigma(c->eps, c->mask4, c->im4, c->nonas);
@@ -596,7 +645,7 @@ double orc_chain_prologue_draw(orc_chain* c, int it) {
 /* bayes.cpp:358-367: adopt mu, subtract it, shuffle, reset counters */
 void orc_chain_prologue_apply(orc_chain* c, double mu) {
     c->mu = mu;
-    orc_offset_epsilon(c->eps, -c->mu, c->mask4, c->im4);
+    chain_offset(c, -c->mu);
     if (c->shuffle) orc_rng_shuffle(c->mimic_hydra ? &c->dist_d : &c->dist_m, c->midx, c->M);
     for (int g = 0; g < c->G; g++) c->m0[g] = 0;
     for (int i = 0; i < c->G * c->K; i++) c->cass[i] = 0;
@@ -680,7 +729,7 @@ static int chain_marker_decide(orc_chain* c, int mloc, double d3[3]) {
 static void chain_marker_step(orc_chain* c, int mloc) {
     double d3[3];
     if (chain_marker_decide(c, mloc, d3)) {
-        orc_update_epsilon(c->eps, d3, &c->bed[(size_t)mloc * c->mbytes], c->mask4, c->im4);
+        chain_update(c, d3, &c->bed[(size_t)mloc * c->mbytes]);
         c->n_updates++;
     }
 }
@@ -817,8 +866,7 @@ void orc_ps_iterate(orc_chain** ch, int R, int it) {
         for (int dst = 0; dst < R; dst++)
             for (int r = 0; r < R; r++)
                 if (share[r])
-                    orc_update_epsilon(ch[dst]->eps, d3[r], &ch[r]->bed[(size_t)mloc[r] * ch[r]->mbytes],
-                                       ch[dst]->mask4, ch[dst]->im4);
+                    chain_update(ch[dst], d3[r], &ch[r]->bed[(size_t)mloc[r] * ch[r]->mbytes]);
     }
     int* cass = (int*)calloc((size_t)(G * K), sizeof(int));
     double* bsq = (double*)calloc((size_t)G, sizeof(double));

@@ -62,6 +62,12 @@ void   orc_marker_stats_canon(const uint8_t* bed, int N, int M, int mbytes, cons
                               int nonas, double* mave, double* msig);
 void   orc_marker_counts(const uint8_t* bedcol, int mbytes, const uint8_t* mask4, int64_t cnt[4]);
 void   orc_split2(double x, double* q1, double* q2);   /* the 2-level pre-rounding */
+/* the canon residual lives on the grid 2^-44 (exact doubles; updates are exact additions) */
+double orc_grid(double x);
+void   orc_grid_array(double* x, int n);
+void   orc_update_epsilon_canon(double* eps, const double* dbeta3, const uint8_t* bedcol,
+                                const uint8_t* mask4, int im4);       /* phenotype.cpp:375-390 on the grid */
+void   orc_offset_epsilon_canon(double* eps, double offset, const uint8_t* mask4, int im4);
 double orc_exp(double x);                              /* the path's exp(), shared spec */
 
 /* ---- phenotype preparation (phenotype.cpp:587-673) ---- */

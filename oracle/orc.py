@@ -53,6 +53,10 @@ _SIGS = {
     "orc_dot_product_canon": (C.c_double, [c_u8_p, c_double_p, C.c_int, C.c_double, C.c_double]),
     "orc_update_epsilon": (None, [c_double_p, c_double_p, c_u8_p, c_u8_p, C.c_int]),
     "orc_offset_epsilon": (None, [c_double_p, C.c_double, c_u8_p, C.c_int]),
+    "orc_update_epsilon_canon": (None, [c_double_p, c_double_p, c_u8_p, c_u8_p, C.c_int]),
+    "orc_offset_epsilon_canon": (None, [c_double_p, C.c_double, c_u8_p, C.c_int]),
+    "orc_grid": (C.c_double, [C.c_double]),
+    "orc_grid_array": (None, [c_double_p, C.c_int]),
     "orc_epsilon_sumsqr": (C.c_double, [c_double_p, C.c_int]),
     "orc_epsilon_sumsqr_canon": (C.c_double, [c_double_p, C.c_int]),
     "orc_epsilon_sigma": (C.c_double, [c_double_p, c_u8_p, C.c_int, C.c_int]),
@@ -161,6 +165,13 @@ def phen_prepare(y, isna):
     nonas = C.c_int(0)
     lib().orc_phen_prepare(_dp(y), _bp(isna), N, _dp(eps), _bp(mask4), C.byref(nonas))
     return eps, mask4, nonas.value
+
+
+def grid(x):
+    """The canon residual's grid: x rounded to the nearest multiple of 2^-44 (ties to even)."""
+    a = np.array(x, dtype=np.float64, copy=True).reshape(-1)
+    lib().orc_grid_array(_dp(a), a.shape[0])
+    return a if np.ndim(x) else float(a[0])
 
 
 class Chain:

@@ -85,8 +85,9 @@ def test_full_width_properties(gpu):
     L = orc.lib()
     n4 = ctx.mbytes
     cols = ctx.download_bed(0, 4)
+    eps_grid = orc.grid(eps)                       # what upload_trait stored: the residual on its 2^-44 grid
     for m in range(4):
-        want = L.orc_dot_product_canon(cols[m].ctypes.data_as(orc.c_u8_p), eps.ctypes.data_as(orc.c_double_p),
+        want = L.orc_dot_product_canon(cols[m].ctypes.data_as(orc.c_u8_p), eps_grid.ctypes.data_as(orc.c_double_p),
                                        n4, mave[m], msig[m])
         assert ctx.dot_product(m, mave[m], msig[m]) == want
     # one full sweep: every marker visited once, residual stays 0 at NA individuals, and the

@@ -49,7 +49,7 @@ def test_dot_update_offset_sums(gpu, name):
     L = orc.lib()
     n4 = cases.im4_of(case.N)
     mave, msig = ctx.compute_markers_statistics(0)
-    host = eps.copy()
+    host = orc.grid(eps)                          # the library keeps the residual on the grid 2^-44 (gm_common.h)
     hp = host.ctypes.data_as(orc.c_double_p)
     mp = mask4.ctypes.data_as(orc.c_u8_p)
     rng = np.random.default_rng(3)
@@ -62,11 +62,11 @@ def test_dot_update_offset_sums(gpu, name):
         assert abs(got - ref) <= 1e-12 * np.sqrt(case.N)
         d3 = np.array([rng.normal(0, 0.05), mave[m], msig[m]])
         ctx.update_epsilon(d3, int(m))
-        L.orc_update_epsilon(hp, d3.ctypes.data_as(orc.c_double_p), col, mp, n4)
+        L.orc_update_epsilon_canon(hp, d3.ctypes.data_as(orc.c_double_p), col, mp, n4)
         if step % 4 == 0:
             off = float(rng.normal(0, 0.01))
             ctx.offset_epsilon(off)
-            L.orc_offset_epsilon(hp, off, mp, n4)
+            L.orc_offset_epsilon_canon(hp, off, mp, n4)
     dev = ctx.get_epsilon(0)
     assert np.array_equal(dev, host), "residual after update/offset differs"
     assert np.all(dev[np.repeat((mask4[:, None] >> np.arange(4)) & 1, 1).ravel() == 0] == 0.0)
@@ -132,6 +132,7 @@ def test_residual_exchange_is_exact(gpu):
     case = cases.CASE_BY_NAME["ragged"]
     inp = cases.make_inputs(case)
     ctx, eps, mask4, nonas = _setup(case, inp)
+    eps = orc.grid(eps)                            # as stored by upload_trait
     ctx.eps_snapshot(0)
     mave, msig = ctx.compute_markers_statistics(0)
     ctx.update_epsilon(np.array([0.0123, mave[5], msig[5]]), 5)
