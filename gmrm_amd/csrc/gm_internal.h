@@ -9,8 +9,9 @@
 namespace gm {
 
 constexpr int SW_TPB  = 256;   // threads per workgroup of the sweep kernel (4 wavefronts)
-constexpr int SW_VMAX = 256;   // exchanged values per batch: 4 per marker (sa1,sa2,sb1,sb2; <= 64 markers) or
-                               // 2 per marker + 2 per batch in the no-missing-genotype layout (<= 120 markers)
+constexpr int SW_VMAX = 384;   // exchanged values per batch: 4 per marker (sa1,sa2,sb1,sb2) or 2 per marker + 2 per batch in the
+                               // no-missing-genotype layout (<= 120 markers), plus one per marker behind a crossed stop
+constexpr int NSTOP = 2;       // markers with a non-zero effect the walk may cross inside one batch (sweep.hip, "continuation")
 constexpr int KMAX = 8;
 constexpr int GMAX = 64;
 
@@ -49,6 +50,11 @@ struct SweepArgs {
     int spec_factor16;             // speculate when EMA >= spec_factor16/16 batches (default 64 = 4x: rarely pays)
     int miss_mode;                 // markers with a missing genotype among the phenotyped individuals: 0 none, 1 some, 2 all
     unsigned long long spin_ticks; // every grid-wide wait gives up after this many s_memrealtime ticks (100 MHz)
+    // LDS carve of this launch (sweep.hip, carve_for: depends on G, K): byte offsets of the component counts, the per-group
+    // tables, the planes and the genotype ring; ring capacity in order positions and the multiplier of `% rpos`
+    int lds_cass, lds_tab, lds_pln, lds_ring, rpos;
+    unsigned rpos_magic;
+    int cross;                     // 1: the walk may cross markers whose effect was non-zero (needs the marker statistics' counts)
 };
 
 // sweep.hip

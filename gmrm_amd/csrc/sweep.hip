@@ -66,52 +66,68 @@ namespace gm {
 template <int R> struct Geo {
     static constexpr int SB = SW_TPB * R;                 // slice bytes per workgroup (= genotype bytes = plane records)
     static constexpr int CPP = SB / 16;                   // 16-byte chunks per position
-    static constexpr int RPOS = R == 4 ? 96 : 240;        // ring capacity in order positions
-    static constexpr int BMAXF = RPOS / 2;                // markers per batch, no-missing layout (2 values/marker)
+    static constexpr int RPOS_MAX = R == 4 ? 96 : 240;    // ring capacity in order positions: at most this, and what the LDS left by the
+                                                          // per-group tables holds (SweepArgs::rpos, sweep_carve below)
+    static constexpr int BMAXF = RPOS_MAX / 2;            // markers per batch, no-missing layout (2 values/marker)
     static constexpr int NL = 192;                        // loader threads (wavefronts 1-3)
     static constexpr int PPI = NL / CPP;                  // positions covered by one load instruction
     static constexpr int PFG = 4;                         // loads per wave-uniform branch
     static constexpr int PFN = ((BMAXF + PPI - 1) / PPI + PFG - 1) / PFG * PFG;   // loads per loader thread per round
-    // Digit plane n (one byte per individual) starts at n * PSTRIDE + (n >> 2) * 64 bytes: in phase A a 16-lane
-    // LDS access group holds 8 planes x 2 lane groups (64 bytes apart) reading 16 bytes each, and these
-    // offsets put the 16 reads on 16 different bank quads (n * 16 + (n >> 2) * 64 + kg * 64 bytes, mod 256).
+    // Planes of operand B (one byte per individual): the seven digit planes of the residual (four signed base-256 digits of
+    // its part on the 2^-22 grid, three of the rest on the 2^-44 grid) and two planes for the genotype values of markers
+    // the walk may cross (NSTOP).  Plane n starts at n * PSTRIDE + (n >> 2) * 64 bytes (n < 7), stop plane s at
+    // (7 + s) * PSTRIDE + 64: in phase A a 16-lane LDS access group reads 16 bytes of each plane, and these offsets
+    // put the reads of the nine planes on different bank quads (0,16,32,48,128,144,160,176,192 mod 256).
     static constexpr int PSTRIDE = 4 * SB + 16;
-    static constexpr int PLANES = 8 * PSTRIDE + 64;       // bytes of the eight planes
+    static constexpr int NPLANES = 7 + NSTOP;
+    static constexpr int PLANES = NPLANES * PSTRIDE + 64; // bytes of all planes
     static_assert(NL % CPP == 0 && PPI >= 1, "loader mapping");
-    static_assert(2 * BMAXF + 2 <= SW_VMAX, "exchange rows");
+    static_assert(2 * BMAXF + 2 + BMAXF <= SW_VMAX, "exchange rows");
 };
 
 // ---- LDS carve (bytes, all multiples of 16) --------------------------------------------
-constexpr int L_VAL  = 64;                      // double[4]    update table of the stopping marker
+constexpr int L_VAL  = 64;                      // (free)
 constexpr int L_CTL  = 96;                      // int[16]      control words
-constexpr int L_RED  = 160;                     // double[4]    reducer scratch
-constexpr int L_WSQ  = 192;                     // double[4][2] per-wavefront sum of q1 / q2
-constexpr int L_M    = 256;                     // diagnostic stamps (64 B at +64)
+constexpr int L_RED  = 160;                     // double[8]    reducer scratch (two rows)
+constexpr int L_WSQ  = 224;                     // double[4][2] per-wavefront sum of q1 / q2
+constexpr int L_M    = 288;                     // diagnostic stamps (64 B at +64)
 constexpr int L_RNG0 = 416;                     // uint32[624]  current MT block (untempered)
 constexpr int L_RNG1 = L_RNG0 + 2496;           // uint32[624]  next MT block
-constexpr int L_CASS = L_RNG1 + 2496;           // int[GMAX*KMAX]
-constexpr int L_SUM  = L_CASS + GMAX * KMAX * 4;   // int64[SW_VMAX]  per-batch integer sums of this workgroup
+constexpr int L_SUM  = L_RNG1 + 2496;           // int64[SW_VMAX]  per-batch integer sums of this workgroup
 constexpr int TAB_LDS = 320;                    // group tables up to 320 doubles live in LDS, larger ones stay in HBM/L2
-constexpr int L_TAB  = L_SUM + SW_VMAX * 8;     // double[TAB_LDS] per-group tables
 constexpr int META_POS = 256;                   // per-marker inputs of the sampling step, ring over order positions
-constexpr int L_META = L_TAB + TAB_LDS * 8;     // int m[256], int g[256], double beta[256], mave[256], msig[256]
+constexpr int L_META = L_SUM + SW_VMAX * 8;     // int m[256], int g[256], double beta[256], mave[256], msig[256]
 constexpr int L_NM   = L_META + META_POS * 32;  // uint8[256]: "no missing genotype" flag of the marker at each ring position
 constexpr int L_TOT  = L_NM + META_POS;         // double[SW_VMAX]: the batch totals as wavefront 0 fetched them
 constexpr int L_ZSP  = L_TOT + SW_VMAX * 8;     // int64[16][2]: missing-genotype terms of a batch's few dirty markers (sparse_z)
 constexpr int L_ZNX  = L_ZSP + 16 * 16;         // double[129] (+ pad): the x table of the normal ziggurat (gm_rng.h), copied at kernel start
-constexpr int L_PLN  = L_ZNX + 130 * 8;         // uint8[8][PSTRIDE]: digit planes of the residual (operand B order)
-template <int R> constexpr int l_ring() { return L_PLN + Geo<R>::PLANES; }
-static_assert(L_PLN % 16 == 0, "LDS carve");
-// Request > 80 KiB so that exactly one workgroup fits per CU.
-constexpr int L_MIN = 84 * 1024;
-template <int R> constexpr int lds_total() {
-    return (l_ring<R>() + Geo<R>::RPOS * Geo<R>::SB) > L_MIN ? (l_ring<R>() + Geo<R>::RPOS * Geo<R>::SB) : L_MIN;
+constexpr int L_UPD  = L_ZNX + 130 * 8;         // the residual updates of the round: int n, pos[3]; double val[3][4] (by ring code)
+constexpr int L_VAR  = L_UPD + 16 + 96 + 16;    // from here on the carve depends on G, K (sweep_carve): component counts int[G*K],
+                                                // per-group tables double[G*(1+3K)] (if they fit TAB_LDS), the planes, the genotype ring
+static_assert(L_VAR % 16 == 0, "LDS carve");
+constexpr int L_MIN = 84 * 1024;                // request > 80 KiB so that exactly one workgroup fits per CU
+constexpr int L_TOTAL = 160 * 1024;
+
+// The part of the carve that depends on the launch (number of groups and components): offsets and the ring capacity.
+struct Carve { int cass, tab, pln, ring, rpos; unsigned magic; };
+template <int R> static Carve carve_for(int G, int K) {
+    Carve c;
+    c.cass = L_VAR;
+    c.tab = c.cass + (G * K * 4 + 15) / 16 * 16;
+    const int tabd = G * (1 + 3 * K);
+    c.pln = c.tab + (tabd <= TAB_LDS ? (tabd * 8 + 15) / 16 * 16 : 0);
+    c.ring = c.pln + Geo<R>::PLANES;
+    int rp = (L_TOTAL - c.ring) / Geo<R>::SB;
+    if (rp > Geo<R>::RPOS_MAX) rp = Geo<R>::RPOS_MAX;
+    c.rpos = rp & ~1;
+    c.magic = (unsigned)((1ull << 32) / (unsigned)c.rpos) + 1u;       // p % rpos = p - rpos * umulhi(p, magic) for p < 2^32 / rpos
+    return c;
 }
-static_assert(lds_total<1>() <= 160 * 1024 && lds_total<2>() <= 160 * 1024 && lds_total<4>() <= 160 * 1024, "LDS budget");
+template <int R> constexpr int lds_total() { return L_TOTAL; }
 
 enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD, C_TOTF, C_RANGE, C_PLN };
 
-size_t sweep_lds_bytes() { return (size_t)lds_total<2>(); }   // the largest of the three carves
+size_t sweep_lds_bytes() { return (size_t)L_TOTAL; }
 
 // Every word another workgroup reads or writes inside the launch is accessed through a
 // GLOBAL (address space 1) agent-scope atomic: global_load/store ... sc1, never flat_.
@@ -147,6 +163,20 @@ __device__ __forceinline__ void get_row4(const unsigned long long* base, int lan
                  "global_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(g) : "memory");
+}
+
+// the same for up to 384 values (a batch with markers behind a crossed stop, or more than 63 dirty markers)
+__device__ __forceinline__ void get_row6(const unsigned long long* base, int lane, u32x4 (&d)[6]) {
+    const unsigned long long* g = base + 2 * lane;
+    const unsigned long long* g2 = g + 512;      // + 4096 bytes: the instruction offset is 13-bit signed
+    asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
+                 "global_load_dwordx4 %1, %6, off offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off offset:2048 sc1\n\t"
+                 "global_load_dwordx4 %3, %6, off offset:3072 sc1\n\t"
+                 "global_load_dwordx4 %4, %7, off sc1\n\t"
+                 "global_load_dwordx4 %5, %7, off offset:1024 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]) : "v"(g), "v"(g2) : "memory");
 }
 
 // ---- cross-lane helpers for the wavefront reductions (gfx950: v_permlane{16,32}_swap, DPP) ----
@@ -447,11 +477,11 @@ __device__ __forceinline__ Draws sample_prepare(int nb, char* smem, TP tab, int 
 template <int K, class TP>
 __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
                                                   const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
-                                                  const Draws draws, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer) {
+                                                  const Draws draws, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass) {
     const int lane = threadIdx.x & 63;
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
-    double* s_val = reinterpret_cast<double*>(smem + L_VAL);
-    int* s_cass = reinterpret_cast<int*>(smem + L_CASS);
+    double* s_val = reinterpret_cast<double*>(smem + L_UPD + 16);
+    int* s_cass = reinterpret_cast<int*>(smem + l_cass);
     LdsStream rs{reinterpret_cast<const uint32_t*>(smem + L_RNG0), reinterpret_cast<const uint32_t*>(smem + L_RNG1),
                  ctl[C_CURSOR], &ctl[C_RNGERR]};
 
@@ -578,8 +608,8 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
 template <int K, class TP>
 __device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
                                           const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
-                                          double p0, double p1, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer) {
-    sample_batch_body<K>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tot0, tot1, Draws{p0, p1}, sigmae, inv2sige, nm1, out, writer);
+                                          double p0, double p1, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass) {
+    sample_batch_body<K>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tot0, tot1, Draws{p0, p1}, sigmae, inv2sige, nm1, out, writer, l_cass);
 }
 
 // rank of batch position p among the dirty markers of the batch (dm0: positions 0..63, dm1: 64..127)
@@ -602,19 +632,35 @@ __device__ __forceinline__ bool poll_totals(int nb, int nv, unsigned long long d
     Spin sp;
     sp.start(spin_limit);
     bool bad = false;
-    u32x4 d[4];
-    for (;;) {
-        get_row4(Ttg, lane, d);
-        bool ok = true;
+    if (nv <= 256) {                             // (uniform) the usual case: four 16-byte loads per lane cover the row
+        u32x4 d[4];
+        for (;;) {
+            get_row4(Ttg, lane, d);
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (64 * k + lane < nv) ok &= (d[k].y == tag && d[k].w == tag);
+            if (__all(ok)) break;
+            if (sp.expired(abort_word)) { bad = true; break; }
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (64 * k + lane < nv) ok &= (d[k].y == tag && d[k].w == tag);
-        if (__all(ok)) break;
-        if (sp.expired(abort_word)) { bad = true; break; }
-    }
+            s_tot[64 * k + lane] = __longlong_as_double((long long)(((unsigned long long)d[k].z << 32) | d[k].x));
+    } else {
+        u32x4 d[6];
+        for (;;) {
+            get_row6(Ttg, lane, d);
+            bool ok = true;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-        s_tot[64 * k + lane] = __longlong_as_double((long long)(((unsigned long long)d[k].z << 32) | d[k].x));
+            for (int k = 0; k < 6; k++)
+                if (64 * k + lane < nv) ok &= (d[k].y == tag && d[k].w == tag);
+            if (__all(ok)) break;
+            if (sp.expired(abort_word)) { bad = true; break; }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            s_tot[64 * k + lane] = __longlong_as_double((long long)(((unsigned long long)d[k].z << 32) | d[k].x));
+    }
     Totals t0{0.0, 0.0, 0.0, 0.0}, t1{0.0, 0.0, 0.0, 0.0};
     const double sq1 = s_tot[2 * nb], sq2 = s_tot[2 * nb + 1];
     if ((dm0 | dm1) == 0ull) {                   // (uniform) the usual case: no dirty marker in the batch
@@ -772,7 +818,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     using GE = Geo<R>;
     constexpr int NI = 4 * R;                        // individuals per thread
     constexpr int ND = NI / 4;                       // dwords of a column slice a thread takes its genotypes from
-    constexpr int SB = GE::SB, CPP = GE::CPP, RPOS = GE::RPOS, PPI = GE::PPI, PFN = GE::PFN, PFG = GE::PFG;
+    constexpr int SB = GE::SB, CPP = GE::CPP, PPI = GE::PPI, PFN = GE::PFN, PFG = GE::PFG;
+    const int RPOS = a.rpos;                         // ring capacity (positions): what the LDS left by the per-group tables holds
+    const unsigned rpos_magic = a.rpos_magic;
+    auto rmod = [&](int p) -> int { return p - RPOS * (int)__umulhi((unsigned)p, rpos_magic); };   // p % RPOS
     constexpr int SS = CPP / 4;                      // super-steps: 4 chunks = 256 individuals, one chunk per lane group
     constexpr int PST = GE::PSTRIDE;                 // bytes per digit plane
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wg = blockIdx.x;
@@ -780,21 +829,21 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // FAST: every marker of the block is free of missing genotypes among the phenotyped individuals (host:
     // all_nomiss) -- 2 exchanged values per marker and the code for missing genotypes is not even compiled in.
     // Otherwise the markers' flags decide per marker (2 more values) and per tile of 16 (a second MFMA set).
-    const int BMAX = GE::BMAXF;                      // cap of the batch-size estimate (dirty markers shorten a batch: 2 more slots each)
+    const int BMAX = RPOS / 2;                       // cap of the batch-size estimate: two batches live in the ring (dirty markers shorten a batch: 2 more slots each)
 
-    const double* s_val = reinterpret_cast<const double*>(smem + L_VAL);
+    const double* s_val = reinterpret_cast<const double*>(smem + L_UPD + 16);
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     uint32_t* s_rng0 = reinterpret_cast<uint32_t*>(smem + L_RNG0);
     uint32_t* s_rng1 = reinterpret_cast<uint32_t*>(smem + L_RNG1);
-    int* s_cass = reinterpret_cast<int*>(smem + L_CASS);
+    int* s_cass = reinterpret_cast<int*>(smem + a.lds_cass);
     unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(smem + L_SUM);
     double* s_red = reinterpret_cast<double*>(smem + L_RED);
     double* s_wsq = reinterpret_cast<double*>(smem + L_WSQ);
     long long* s_zsp = reinterpret_cast<long long*>(smem + L_ZSP);
-    double* s_tab = reinterpret_cast<double*>(smem + L_TAB);
-    char* planes = smem + L_PLN;
+    double* s_tab = reinterpret_cast<double*>(smem + a.lds_tab);
+    char* planes = smem + a.lds_pln;
     const bool tab_in_lds = G * (1 + 3 * K) <= TAB_LDS;
-    char* ring = smem + l_ring<R>();
+    char* ring = smem + a.lds_ring;
     unsigned* abort_word = a.cnt + 64;
     const unsigned long long spin_limit = a.spin_ticks;
     unsigned long long* Pg = reinterpret_cast<unsigned long long*>(a.P);
@@ -804,7 +853,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     for (int i = tid; i < G * K; i += SW_TPB) s_cass[i] = 0;
     if (tab_in_lds)
         for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];
-    s_sum[tid] = 0ull;
+    for (int i = tid; i < SW_VMAX; i += SW_TPB) s_sum[i] = 0ull;
 #ifdef GM_SWEEP_PROF
     if (tid < 8) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[tid] = 0ull;
 #endif
@@ -847,7 +896,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     auto refresh_planes = [&]() {
         double sq1 = 0.0, sq2 = 0.0;
         bool big = false;
-        uint32_t pl[8][ND];
+        uint32_t pl[7][ND];
 #pragma unroll
         for (int g4 = 0; g4 < ND; g4++) {
             uint32_t z1[4], z2[4];
@@ -859,15 +908,15 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 split2(x, q1, q2);
                 sq1 += q1; sq2 += q2;
                 z1[j] = signed_digits((int)(q1 * 0x1p22));      // exact: q1 is a multiple of 2^-22, |q1| <= 2^8
-                z2[j] = signed_digits((int)(q2 * 0x1p53));      // exact: q2 is a multiple of 2^-53, |q2| <= 2^-23
+                z2[j] = signed_digits((int)(q2 * GRID_INV));    // exact: q2 is a multiple of 2^-44 (the residual's grid), |q2| <= 2^-23: three digits
             }
             const uint4 d1 = digit_planes(z1[0], z1[1], z1[2], z1[3]);
             const uint4 d2 = digit_planes(z2[0], z2[1], z2[2], z2[3]);
             pl[0][g4] = d1.x; pl[1][g4] = d1.y; pl[2][g4] = d1.z; pl[3][g4] = d1.w;
-            pl[4][g4] = d2.x; pl[5][g4] = d2.y; pl[6][g4] = d2.z; pl[7][g4] = d2.w;
+            pl[4][g4] = d2.x; pl[5][g4] = d2.y; pl[6][g4] = d2.z;
         }
 #pragma unroll
-        for (int n = 0; n < 8; n++) {
+        for (int n = 0; n < 7; n++) {
             char* dst = planes + n * PST + (n >> 2) * 64 + p0w;
             if constexpr (ND == 1) *reinterpret_cast<uint32_t*>(dst) = pl[n][0];
             else if constexpr (ND == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pl[n][0], pl[n][1]);
@@ -892,7 +941,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // workgroup took twice as long to issue its loads and trailed every round by 2 us.
     const size_t cb = !loader ? 0 : (cb_true < a.stride ? cb_true : (cb_true >= (size_t)SB ? cb_true - SB : cb_true % a.stride));
     auto ring_chunk = [&](int p, int chunk) -> uint4* {   // 16-byte chunk `chunk` of order position p
-        return reinterpret_cast<uint4*>(ring + (size_t)((unsigned)p % (unsigned)RPOS) * SB + 16 * (chunk ^ (p & (CPP - 1))));
+        return reinterpret_cast<uint4*>(ring + (size_t)rmod(p) * SB + 16 * (chunk ^ (p & (CPP - 1))));
     };
     u32x4 pf[PFN];                                    // in flight / parked in AGPRs (inline asm below owns them)
     int pos = 0;
@@ -970,7 +1019,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // slot of this thread's first position; later ones are PPI apart (one conditional wrap each)
             const int p_first = hi + lpj;
-            const int s_first = (int)((unsigned)p_first % (unsigned)RPOS);
+            const int s_first = rmod(p_first);
 #pragma unroll
             for (int c8 = 0; c8 < PFN; c8 += PFG) {
                 if (c8 * PPI < nc) {
@@ -1164,7 +1213,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     else    { m = 64 + __ffsll((long long)r1) - 1; r1 &= r1 - 1ull; }
                     if ((r & 3) == wave) {
                         const int pm = p0 + m;
-                        const char* slice = ring + (size_t)((unsigned)pm % (unsigned)RPOS) * SB;
+                        const char* slice = ring + (size_t)rmod(pm) * SB;
                         const int swz = pm & (CPP - 1);
                         long long z1 = 0, z2 = 0;
 #pragma unroll
@@ -1181,7 +1230,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #pragma unroll
                                 for (int n = 0; n < 4; n++) {
                                     v1 += (int)*reinterpret_cast<const signed char*>(planes + n * PST + posn) << (8 * n);
-                                    v2 += (int)*reinterpret_cast<const signed char*>(planes + (n + 4) * PST + 64 + posn) << (8 * n);
+                                    if (n < 3) v2 += (int)*reinterpret_cast<const signed char*>(planes + (n + 4) * PST + 64 + posn) << (8 * n);
                                 }
                                 z1 += v1; z2 += v2;
                             }
@@ -1210,7 +1259,11 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         const int wt = wave & (tsplit - 1), wk = wave / tsplit;
         const int ss_lo = wk * (SS / ksplit);               // first super-step of this wavefront's part of the slice
         const int mrow = lane & 15, kg = lane >> 4;
-        const char* pbase = planes + (lane & 7) * PST + ((lane & 7) >> 2) * 64 + kg * 64;   // columns 8..15 of B repeat 0..7 (their results are dropped)
+        // operand B: columns 0..6 = the digit planes, 8 and 9 = the planes of the markers the walk may cross; the others
+        // (7, 10..15) read plane 0 and their results are dropped
+        const int ncol = lane & 15;
+        const int poff = ncol < 7 ? ncol * PST + (ncol >> 2) * 64 : ((ncol == 8 || ncol == 9) ? (ncol - 1) * PST + 64 : 0);
+        const char* pbase = planes + poff + kg * 64;
         constexpr uint32_t M0 = 0x03030303u, M1 = 0x01010101u;
         // One pass = ONE or TWO tiles of 16 markers (t and t + tsplit: operand B is read once for both) x NS
         // super-steps of the slice starting at ss_lo.  NS and the tile count are compile-time so that the body is
@@ -1225,7 +1278,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             for (int q = 0; q < NTL; q++) {
                 const int mk = 16 * (t + q * tsplit) + mrow;
                 const int pl = p0 + (mk < nb ? mk : nb - 1);          // idle rows shadow the last marker (their sums are dropped)
-                sl0[q] = lds_addr(ring + (size_t)((unsigned)pl % (unsigned)RPOS) * SB);
+                sl0[q] = lds_addr(ring + (size_t)rmod(pl) * SB);
                 swz[q] = pl & (CPP - 1);
             }
             const uint32_t pb0 = lds_addr(pbase) + (uint32_t)ss_lo * 256u;
@@ -1281,7 +1334,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int m = 16 * (t + q * tsplit) + 4 * kg + r;
-                    const int x = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);   // sum c' * digit (c' = a wherever the residual is not 0)
+                    const int xr = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);  // sum c' * digit (c' = a wherever the residual is not 0)
+                    const int x = n == 7 ? 0 : xr;                                      // the second part has three digits: column 7 is not a plane
                     const long long sx = quad_sum64((long long)x << (8 * (n & 3)));
                     if (TF) {
                         if ((n & 3) == 0 && n < 8 && m < nb) atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)sx);
@@ -1289,7 +1343,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                         // a = c' - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
                         // slice's sum of d is added at the publish.  (A clean marker in this tile has Z = 0: code 11
                         // occurs for it only where the residual is 0.)
-                        const int z = zcc0[q][r] + (zcc1[q][r] >> 2) + (zcc2[q][r] >> 4);
+                        const int zr = zcc0[q][r] + (zcc1[q][r] >> 2) + (zcc2[q][r] >> 4);
+                        const int z = n == 7 ? 0 : zr;
                         const long long sz = quad_sum64((long long)z << (8 * (n & 3)));
                         if ((n & 3) == 0 && n < 8 && m < nb) {
                             atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)(sx - 3 * sz));
@@ -1326,29 +1381,29 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         lds_barrier();                                // the LDS sums are complete (prefetches stay in flight)
         PA(3);
         const int nv = 2 * nb + 2 + 2 * nd;
-        if (tid < nv) {
+        for (int vi = tid; vi < nv; vi += SW_TPB) {           // up to SW_VMAX values, 256 threads
             double tot;
-            if (tid >= 2 * nb && tid < 2 * nb + 2) {  // sum q1, sum q2 over the slice
-                const int w2 = tid - 2 * nb;
+            if (vi >= 2 * nb && vi < 2 * nb + 2) {  // sum q1, sum q2 over the slice
+                const int w2 = vi - 2 * nb;
                 tot = s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2];
             } else {
-                long long v = (long long)s_sum[tid];
+                long long v = (long long)s_sum[vi];
                 if constexpr (MODE == 1) {
                     if (sparse_z) {                   // X - 3 Z for the a-sums of a dirty marker, -Z in its own b-slots
-                        if (tid >= 2 * nb + 2) v -= s_zsp[tid - (2 * nb + 2)];
-                        else if (dirty_at(dm0, dm1, tid >> 1)) v -= 3 * s_zsp[2 * dirty_rank(dm0, dm1, tid >> 1) + (tid & 1)];
+                        if (vi >= 2 * nb + 2) v -= s_zsp[vi - (2 * nb + 2)];
+                        else if (dirty_at(dm0, dm1, vi >> 1)) v -= 3 * s_zsp[2 * dirty_rank(dm0, dm1, vi >> 1) + (vi & 1)];
                     }
                 }
-                if (tid >= 2 * nb + 2) {              // dirty marker: sum b d = sum d - Z, this slice's sum of the exact part as an integer
-                    const int w2 = tid & 1;
+                if (vi >= 2 * nb + 2) {              // dirty marker: sum b d = sum d - Z, this slice's sum of the exact part as an integer
+                    const int w2 = vi & 1;
                     const double dsum = s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2];
-                    v += (long long)(dsum * (w2 ? 0x1p53 : 0x1p22));                // exact: a multiple of the grid, < 2^53 units
+                    v += (long long)(dsum * (w2 ? GRID_INV : 0x1p22));              // exact: a multiple of the grid, < 2^53 units
                 }
                 // |sum| < 2^53 grid units: the conversion and the power-of-two scaling are exact
-                tot = (double)v * ((tid & 1) ? 0x1p-53 : 0x1p-22);
-                s_sum[tid] = 0ull;
+                tot = (double)v * ((vi & 1) ? GRID : 0x1p-22);
+                s_sum[vi] = 0ull;
             }
-            put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)tid * a.Wpad + wg), b.gen + 1u, tot);
+            put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)vi * a.Wpad + wg), b.gen + 1u, tot);
         }
         b.nv = nv;
         PA(4);
@@ -1483,19 +1538,19 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 // ONE copy of the step per table address space (only one of them runs in a launch)
                 auto run_step = [&](auto tabq) {
                     if (K == 4) {
-                        sample_batch_body<4>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, draws, a.sigmae, a.inv2sige, a.nm1, so, wg == 0);
+                        sample_batch_body<4>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, draws, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass);
                     } else {
                         // out-of-line copies take their inputs by address: hand them copies, so that the
                         // loop-carried lane inputs themselves stay in registers (no scratch round trips)
                         const LaneIn lc0 = li_cur0, lc1 = li_cur1;
                         const Totals tc0 = tot0, tc1 = tot1;
                         switch (K) {
-                            case 2: sample_batch<2>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                            case 3: sample_batch<3>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                            case 5: sample_batch<5>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                            case 6: sample_batch<6>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                            case 7: sample_batch<7>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
-                            default: sample_batch<8>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0); break;
+                            case 2: sample_batch<2>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
+                            case 3: sample_batch<3>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
+                            case 5: sample_batch<5>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
+                            case 6: sample_batch<6>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
+                            case 7: sample_batch<7>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
+                            default: sample_batch<8>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
                         }
                     }
                 };
@@ -1526,7 +1581,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             n_upd++;
             const int ps = pos + ctl[C_SUPD];
             // this thread's ND dwords of the slice: field o_fld of each byte is one of its individuals (ring codes c')
-            const char* own = ring + (size_t)((unsigned)ps % (unsigned)RPOS) * SB + 16 * (o_chunk ^ (ps & (CPP - 1))) + o_jb;
+            const char* own = ring + (size_t)rmod(ps) * SB + 16 * (o_chunk ^ (ps & (CPP - 1))) + o_jb;
 #pragma unroll
             for (int d = 0; d < ND; d++) {
                 const uint32_t cd = (*reinterpret_cast<const uint32_t*>(own + 4 * d) | na_or[d]) >> (2 * o_fld);
@@ -1598,8 +1653,12 @@ int sweep_pick_R(size_t stride, int max_wg, int* W_out) {
     return -1;
 }
 
-template <int R, int MODE> static hipError_t launch_RF(const SweepArgs& a, hipStream_t st, int grid) {
+template <int R, int MODE> static hipError_t launch_RF(const SweepArgs& a0, hipStream_t st, int grid) {
     const int lds = lds_total<R>();
+    SweepArgs a = a0;
+    const Carve cv = carve_for<R>(a.G, a.K);
+    a.lds_cass = cv.cass; a.lds_tab = cv.tab; a.lds_pln = cv.pln; a.lds_ring = cv.ring; a.rpos = cv.rpos; a.rpos_magic = cv.magic;
+    if (cv.rpos < 32) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_sweep<R, MODE>), dim3(grid), dim3(SW_TPB), lds, st, a);

@@ -37,7 +37,7 @@ python3 - $OUT <<'PY'
 import json, sys, glob, os
 out = sys.argv[1]
 rows = []
-for f in sorted(glob.glob(out + "/shard_*.json"), key=lambda p: -int(os.path.basename(p)[6:-5])):
+for f in sorted(glob.glob(out + "/shard_[0-9]*.json"), key=lambda p: -int(os.path.basename(p)[6:-5])):
     d = json.load(open(f))
     rows.append({"markers": d["config"]["markers_per_gpu"], "ms_per_step": d["ms_per_step"], "kernel_ms_avg": d["roofline"]["kernel_ms_avg"],
                  "host_ms_per_step": d["ms_per_step"] - d["roofline"]["kernel_ms_avg"], "rounds": d["sweep"]["sync_rounds_per_sweep"],
