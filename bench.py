@@ -260,7 +260,7 @@ def main():
         warm_ms.append(max(smp.hyper(t).sweep_device_ms for t in range(T)))
     fence()
     t0 = time.perf_counter()
-    kern_ms, upd, batches, planned, stale = [], [], [], [], []
+    kern_ms, upd, batches, planned, stale, crossed = [], [], [], [], [], []
     for _ in range(a.steps):
         it += 1
         step(it)
@@ -270,6 +270,7 @@ def main():
         batches.append(hy.n_batches)
         planned.append(hy.n_planned_stops)
         stale.append(hy.n_stale_dots)
+        crossed.append(hy.n_crossed_stops)
     fence()
     dt = time.perf_counter() - t0
     per_gpu_kernel_ms = [sum(kern_ms) / max(1, len(kern_ms))]
@@ -322,11 +323,13 @@ def main():
                                                  "what a pure read stream of this data reaches on this GPU"},
             "sweep": {"updates_per_sweep": upd, "sync_rounds_per_sweep": batches,
                       "update_fraction": [u / float(M) for u in upd],
-                      "planned_stops_per_sweep": planned, "stale_dots_per_sweep": stale,
+                      "planned_stops_per_sweep": planned, "stale_dots_per_sweep": stale, "crossed_stops_per_sweep": crossed,
                       "fast_layout_batches_last_sweep": smp.hyper(0).n_fast_batches,
-                      "note": "a round = one batch of dots + one grid-wide exchange; it ends at the first marker whose effect "
-                              "changes.  planned stops: the marker was in the model before the visit (known in advance, the batch "
-                              "ends there); stale dots: computed behind an unplanned stop and thrown away"},
+                      "note": "a round = one batch of dots + one grid-wide exchange.  It ends at the first marker whose effect changes, "
+                              "unless that marker was in the model before the visit and the walk can cross it (crossed stops: the "
+                              "sums behind it are patched exactly inside the round); planned stops: rounds that ended at a marker "
+                              "that was in the model (known in advance, the batch ends there); stale dots: computed behind a stop "
+                              "and thrown away"},
             "rccl_ranks": world if use_pg else 0,
             "per_gpu": {"kernel_ms_avg": per_gpu_kernel_ms,
                         "roofline_frac": [(float(gmrm_amd.block_of_markers(Mt, world, r)[1]) * mbytes / (k / 1e3) / 1e9 / HBM_PEAK_GBS) if k > 0 else 0.0

@@ -30,7 +30,8 @@ class SweepIn(C.Structure):
 class SweepOut(C.Structure):
     _fields_ = [("cass", c_int_p), ("rng_state", C.c_uint32 * 624), ("rng_index", C.c_int),
                 ("n_updates", C.c_longlong), ("n_batches", C.c_longlong), ("device_ms", C.c_double),
-                ("n_planned_stops", C.c_longlong), ("n_stale_dots", C.c_longlong), ("n_fast_batches", C.c_longlong)]
+                ("n_planned_stops", C.c_longlong), ("n_stale_dots", C.c_longlong), ("n_fast_batches", C.c_longlong),
+                ("n_crossed_stops", C.c_longlong)]
 
 
 class SamplerOpts(C.Structure):
@@ -43,7 +44,8 @@ class HyperC(C.Structure):
     _fields_ = [("sigmae", C.c_double), ("mu", C.c_double), ("m0_sum", C.c_int),
                 ("sigmag", C.c_double * GMAX), ("pi_est", C.c_double * (GMAX * KMAX)),
                 ("n_updates", C.c_longlong), ("n_batches", C.c_longlong), ("sweep_device_ms", C.c_double),
-                ("n_planned_stops", C.c_longlong), ("n_stale_dots", C.c_longlong), ("n_fast_batches", C.c_longlong)]
+                ("n_planned_stops", C.c_longlong), ("n_stale_dots", C.c_longlong), ("n_fast_batches", C.c_longlong),
+                ("n_crossed_stops", C.c_longlong)]
 
 
 class GeometryC(C.Structure):

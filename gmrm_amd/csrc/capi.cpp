@@ -118,6 +118,7 @@ static int ctx_create_body(gmrm_ctx* c, int device, int N, int M, int Mt, int S,
     }
     if (const char* e = std::getenv("GMRM_NB_FACTOR16")) { int v = std::atoi(e); if (v >= 8 && v <= 256) c->nb_factor16 = v; }
     if (const char* e = std::getenv("GMRM_SPEC_FACTOR16")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) c->spec_factor16 = v; }
+    if (const char* e = std::getenv("GMRM_CROSS_FRAC16")) { int v = std::atoi(e); if (v >= 1 && v <= 16) c->cross_frac16 = v; }
     if (const char* e = std::getenv("GMRM_SPIN_TIMEOUT_MS")) { int v = std::atoi(e); if (v >= 1 && v <= 60000) c->spin_timeout_ms = v; }
 
     hipError_t e = hipSuccess;
@@ -617,6 +618,10 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.spec_factor16 = c->spec_factor16;
     a.miss_mode = tr.miss_mode;
     if (std::getenv("GMRM_FORCE_MIXED")) a.miss_mode = 1;     // diagnostic: run any block through the per-marker-layout kernel
+    // The walk may cross markers whose effect was non-zero when no marker of the block has a missing genotype among the
+    // phenotyped individuals (then mave * nonas is the integer sum of a marker's genotype values; flags and means come
+    // from gmrm_marker_stats: values set through gmrm_set_marker_stats leave miss_mode at 2).  GMRM_NO_CROSS=1: A/B knob.
+    a.cross = (a.miss_mode == 0 && !std::getenv("GMRM_NO_CROSS")) ? c->cross_frac16 : 0;
     a.spin_ticks = (unsigned long long)c->spin_timeout_ms * 100000ull;      // s_memrealtime ticks (100 MHz)
     // Phenotypes that do not fit side by side share stream 0 and run one after another.
     hipStream_t st = c->tr[t % c->conc].stream;       // conc chains side by side, the others queue behind them
@@ -654,7 +659,7 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
     if (!tr.in_flight) return fail(GMRM_ESTATE, "no sweep in flight for this phenotype");
     tr.in_flight = false;
     if (tr.empty) {
-        if (out) { out->n_updates = 0; out->n_batches = 0; out->device_ms = 0.0; out->n_planned_stops = 0; out->n_stale_dots = 0; out->n_fast_batches = 0;
+        if (out) { out->n_updates = 0; out->n_batches = 0; out->device_ms = 0.0; out->n_planned_stops = 0; out->n_stale_dots = 0; out->n_fast_batches = 0; out->n_crossed_stops = 0;
                    if (out->cass) std::memset(out->cass, 0, sizeof(int) * (size_t)tr.G * tr.K); }
         return GMRM_OK;
     }
@@ -683,7 +688,7 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
         long long st[40];
         HIPCHK(hipMemcpy(st, tr.stats, sizeof(st), hipMemcpyDeviceToHost));
         out->n_updates = st[0]; out->n_batches = st[1]; out->n_planned_stops = st[29]; out->n_stale_dots = st[30];
-        out->n_fast_batches = st[31];
+        out->n_fast_batches = st[31]; out->n_crossed_stops = st[32];
         if (const char* path = std::getenv("GMRM_SWEEP_TRACE")) {
             if (tr.trace) {
                 std::vector<unsigned long long> h((size_t)256 * 64 * 8);

@@ -60,6 +60,7 @@ struct gmrm_ctx {
     int max_resident_wg = 0;        // occupancy query x num_cu for the sweep kernel at this R
     int spin_timeout_ms = 4000;     // bound of every grid-wide wait inside the kernel (env GMRM_SPIN_TIMEOUT_MS)
     bool concurrent = true, have_bed = false, have_groups = false;
+    int cross_frac16 = 9;           // the walk crosses a marker with a non-zero effect when at least this many sixteenths of the batch lie behind it (env GMRM_CROSS_FRAC16)
     int batch_init = 16, nb_factor16 = 24, spec_factor16 = 64;   // sweep schedule knobs (env GMRM_NB_FACTOR16 / GMRM_SPEC_FACTOR16)
 };
 

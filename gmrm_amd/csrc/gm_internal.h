@@ -54,7 +54,8 @@ struct SweepArgs {
     // tables, the planes and the genotype ring; ring capacity in order positions and the multiplier of `% rpos`
     int lds_cass, lds_tab, lds_pln, lds_ring, rpos;
     unsigned rpos_magic;
-    int cross;                     // 1: the walk may cross markers whose effect was non-zero (needs the marker statistics' counts)
+    int cross;                     // > 0: the walk may cross a marker whose effect was non-zero when at least cross/16 of the batch
+                                   // lies behind it (a crossing costs about half a round; 0: never)
 };
 
 // sweep.hip

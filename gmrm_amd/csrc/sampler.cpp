@@ -26,7 +26,7 @@ struct Chain {                       // class Phenotype, the host-resident part
     std::vector<int> midx, cass, m0;
     std::vector<double> sigmag, pi_est, beta_sqn, betas;
     double sigmae = 0.0, mu = 0.0, epssum = 0.0;
-    long long n_updates = 0, n_batches = 0, n_planned = 0, n_stale = 0, n_fastb = 0;
+    long long n_updates = 0, n_batches = 0, n_planned = 0, n_stale = 0, n_fastb = 0, n_cross = 0;
     double sweep_ms = 0.0;
     bool preshuffled = false;        // midx already holds the NEXT iteration's order (shuffled while the GPU swept)
     // host copies the per-step schedule works on (gmrm_sampler_begin_steps .. _end_steps)
@@ -203,7 +203,7 @@ int gmrm_sampler_begin_steps(gmrm_sampler* s, const double* mu_use) {
             if (int r = gmrm_get_acum(ctx, t, c.acum.data())) return r;
             if (int r = gmrm_get_marker_stats(ctx, t, c.mave.data(), c.msig.data())) return r;
         }
-        c.n_updates = 0; c.n_batches = 0; c.n_planned = 0; c.n_stale = 0; c.n_fastb = 0; c.sweep_ms = 0.0;
+        c.n_updates = 0; c.n_batches = 0; c.n_planned = 0; c.n_stale = 0; c.n_fastb = 0; c.n_cross = 0; c.sweep_ms = 0.0;
         c.stepping = true;
     }
     return GMRM_OK;
@@ -328,7 +328,7 @@ int gmrm_sampler_end_sweep(gmrm_sampler* s, int* cass, double* beta_sqn) {
             c.dist_d.idx = out.rng_index;
         }
         c.n_updates = out.n_updates; c.n_batches = out.n_batches; c.sweep_ms = out.device_ms;
-        c.n_planned = out.n_planned_stops; c.n_stale = out.n_stale_dots; c.n_fastb = out.n_fast_batches;
+        c.n_planned = out.n_planned_stops; c.n_stale = out.n_stale_dots; c.n_fastb = out.n_fast_batches; c.n_cross = out.n_crossed_stops;
         if (ctx->M > 0)
             if (int r = gmrm_get_betas(ctx, t, c.betas.data())) { rc = r; continue; }
         std::fill(c.beta_sqn.begin(), c.beta_sqn.end(), 0.0);
@@ -407,7 +407,7 @@ int gmrm_sampler_get(gmrm_sampler* s, int t, gmrm_hyper* out) {
     for (int g = 0; g < s->G; g++) out->sigmag[g] = c.sigmag[g];
     for (int i = 0; i < s->G * s->K; i++) out->pi_est[i] = c.pi_est[i];
     out->n_updates = c.n_updates; out->n_batches = c.n_batches; out->sweep_device_ms = c.sweep_ms;
-    out->n_planned_stops = c.n_planned; out->n_stale_dots = c.n_stale; out->n_fast_batches = c.n_fastb;
+    out->n_planned_stops = c.n_planned; out->n_stale_dots = c.n_stale; out->n_fast_batches = c.n_fastb; out->n_crossed_stops = c.n_cross;
     return GMRM_OK;
 }
 

@@ -94,7 +94,6 @@ constexpr int L_M    = 288;                     // diagnostic stamps (64 B at +6
 constexpr int L_RNG0 = 416;                     // uint32[624]  current MT block (untempered)
 constexpr int L_RNG1 = L_RNG0 + 2496;           // uint32[624]  next MT block
 constexpr int L_SUM  = L_RNG1 + 2496;           // int64[SW_VMAX]  per-batch integer sums of this workgroup
-constexpr int TAB_LDS = 320;                    // group tables up to 320 doubles live in LDS, larger ones stay in HBM/L2
 constexpr int META_POS = 256;                   // per-marker inputs of the sampling step, ring over order positions
 constexpr int L_META = L_SUM + SW_VMAX * 8;     // int m[256], int g[256], double beta[256], mave[256], msig[256]
 constexpr int L_NM   = L_META + META_POS * 32;  // uint8[256]: "no missing genotype" flag of the marker at each ring position
@@ -103,7 +102,7 @@ constexpr int L_ZSP  = L_TOT + SW_VMAX * 8;     // int64[16][2]: missing-genotyp
 constexpr int L_ZNX  = L_ZSP + 16 * 16;         // double[129] (+ pad): the x table of the normal ziggurat (gm_rng.h), copied at kernel start
 constexpr int L_UPD  = L_ZNX + 130 * 8;         // the residual updates of the round: int n, pos[3]; double val[3][4] (by ring code)
 constexpr int L_VAR  = L_UPD + 16 + 96 + 16;    // from here on the carve depends on G, K (sweep_carve): component counts int[G*K],
-                                                // per-group tables double[G*(1+3K)] (if they fit TAB_LDS), the planes, the genotype ring
+                                                // per-group tables double[G*(1+3K)], the planes, the genotype ring
 static_assert(L_VAR % 16 == 0, "LDS carve");
 constexpr int L_MIN = 84 * 1024;                // request > 80 KiB so that exactly one workgroup fits per CU
 constexpr int L_TOTAL = 160 * 1024;
@@ -115,7 +114,7 @@ template <int R> static Carve carve_for(int G, int K) {
     c.cass = L_VAR;
     c.tab = c.cass + (G * K * 4 + 15) / 16 * 16;
     const int tabd = G * (1 + 3 * K);
-    c.pln = c.tab + (tabd <= TAB_LDS ? (tabd * 8 + 15) / 16 * 16 : 0);
+    c.pln = c.tab + (tabd * 8 + 15) / 16 * 16;        // always in LDS: large tables take positions from the ring
     c.ring = c.pln + Geo<R>::PLANES;
     int rp = (L_TOTAL - c.ring) / Geo<R>::SB;
     if (rp > Geo<R>::RPOS_MAX) rp = Geo<R>::RPOS_MAX;
@@ -153,6 +152,16 @@ __device__ __forceinline__ bool get_value(const unsigned long long* g, unsigned 
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(d) : "v"(g) : "memory");
     v = __longlong_as_double((long long)(((unsigned long long)d.z << 32) | d.x));
     return d.y == tag && d.w == tag;
+}
+// two values in one round trip (a reducer workgroup with two rows)
+__device__ __forceinline__ void get_value2(const unsigned long long* g0, const unsigned long long* g1, unsigned tag,
+                                           double& v0, bool& ok0, double& v1, bool& ok1) {
+    u32x4 d0, d1;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %3, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)" : "=&v"(d0), "=&v"(d1) : "v"(g0), "v"(g1) : "memory");
+    if (!ok0 && d0.y == tag && d0.w == tag) { ok0 = true; v0 = __longlong_as_double((long long)(((unsigned long long)d0.z << 32) | d0.x)); }
+    if (!ok1 && d1.y == tag && d1.w == tag) { ok1 = true; v1 = __longlong_as_double((long long)(((unsigned long long)d1.z << 32) | d1.x)); }
 }
 // lane l of a wavefront: values l, 64+l, 128+l, 192+l of one generation's totals in a single round trip
 __device__ __forceinline__ void get_row4(const unsigned long long* base, int lane, u32x4 (&d)[4]) {
@@ -279,8 +288,7 @@ __device__ void block_advance(uint32_t* s0, uint32_t* s1, int* ctl, bool copy) {
 // the step through a pointer of KNOWN address space (a generic pointer compiles to flat loads, each followed
 // by a wait for both memory counters in the middle of the arithmetic).
 template <int K> struct LaneTab { double sg; double denom[K], logpi[K], mhl[K]; };
-typedef const __attribute__((address_space(3))) double* TabLds;      // the tables fit the LDS carve (the usual case)
-typedef const __attribute__((address_space(1))) double* TabGlobal;   // G * (1 + 3K) > TAB_LDS doubles: read from global memory
+typedef const __attribute__((address_space(3))) double* TabLds;      // the tables live in the LDS carve (carve_for)
 template <int K, class TP> __device__ __forceinline__ LaneTab<K> load_tab(TP tab, int G, int g) {
     LaneTab<K> t;
     t.sg = tab[g];
@@ -474,35 +482,105 @@ __device__ __forceinline__ Draws sample_prepare(int nb, char* smem, TP tab, int 
     return d;
 }
 
-template <int K, class TP>
-__device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
-                                                  const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
-                                                  const Draws draws, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass) {
+// ---- walking past a marker whose effect changes ("continuation") ---------------------------------------
+// The residual lives on the grid 2^-44 and a marker's update adds beta_ + a * alpha_ (grid values, gm_common.h) to every
+// phenotyped individual whose genotype is not missing, exactly.  The dot products of the markers behind it therefore
+// change by integers (grid units):
+//     sum_i a_j(i) eps_i  +=  alpha_ * G_sj + beta_ * X_j        G_sj = sum_i a_j(i) a_s(i) na_i,  X_j = sum_i a_j(i) na_i
+//     sum_i eps_i         +=  alpha_ * X_s  + beta_ * nonas
+// for a stopping marker s without missing genotypes among the phenotyped individuals.  G_sj comes out of phase A (the
+// genotype values of s as one more plane of operand B, exchanged like a digit sum), X_j = mave_j * nonas (an integer: the
+// marker statistics' numerator).  The sums are patched as 128-bit integers and handed back as two exact parts of the same
+// kinds as the exchanged ones: the dot product is the nearest double of the exact sum either way.
+__device__ __forceinline__ __int128 exact_sum(double t0, double t1) {     // t0 on the 2^-22 grid (< 2^31), t1 on the 2^-44 grid: grid units
+    return (__int128)((unsigned __int128)(__int128)(long long)(t0 * 0x1p22) << 22) + (__int128)(long long)(t1 * GRID_INV);
+}
+// ... and back: the exact sum s (grid units) as two doubles of the same kinds (t0 a multiple of 2^-22 below 2^31, 0 <= t1 < 2^-22 on
+// the grid), so that the patched sums go through the same f64 expressions as exchanged ones (one rounding of the exact sum)
+__device__ __forceinline__ void exact_split(__int128 s, double& t0, double& t1) {
+    const long long h = (long long)(s >> 22);                             // floor
+    const long long l = (long long)(s - ((__int128)h << 22));             // 0 .. 2^22 - 1
+    t0 = (double)h * 0x1p-22;
+    t1 = (double)l * GRID;
+}
+
+// The residual updates of one round, for phase C: n, then per update the batch position and the four values by ring code.
+struct UpdList { int* n; int* pos; double* val; };
+__device__ __forceinline__ UpdList upd_list(char* smem) {
+    return UpdList{reinterpret_cast<int*>(smem + L_UPD), reinterpret_cast<int*>(smem + L_UPD) + 1, reinterpret_cast<double*>(smem + L_UPD + 16)};
+}
+
+// The state of a walk between its two pieces (below): wave-uniform except where noted.
+struct Walk {
+    int cursor;          // RNG words consumed so far
+    int run;             // markers walked, for the batch-size estimate
+    int nupd, ncross;    // residual updates recorded for phase C; how many of them the walk went past
+    int from;            // first batch position the walk has not passed yet
+    int ndone;
+    bool stopped, planned;
+    bool repeek;         // a stop consumed words of the stream: the prepared draws no longer hold
+    // a stop the walk may cross, met by the first piece and left to the second: its index among the batch's crossable
+    // markers (or -1), its position, the two values of its update in grid units and its sum of genotype values
+    int q, at;
+    long long ai, bi, xs;
+};
+
+// One piece of the walk over a batch.  HOT = true: the piece every round runs -- positions 0..63, then 64..127, until a
+// marker's effect changes; if that marker may be crossed (CONT: it is one of the batch's registered stops) the piece
+// returns with w.q >= 0 instead of ending the round.  HOT = false: the continuation behind such a marker -- it patches
+// the sums of the markers behind it (exact integers, see above) and walks on, crossing further registered stops itself.
+// Two instantiations of the same code: the first stays the straight-line two-pass code the compiler makes of it when
+// nothing can resume inside (its loop-carried state is small), the second is a general loop entered ~0.3 times per round.
+template <int K, bool CONT, bool HOT, class TP>
+__device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, TP tab,
+                                           const LaneIn& lin0, const LaneIn& lin1, Totals& tq0, Totals& tq1,
+                                           const Draws draws, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass,
+                                           int ns, int ps0, int ps1) {
     const int lane = threadIdx.x & 63;
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
-    double* s_val = reinterpret_cast<double*>(smem + L_UPD + 16);
+    const UpdList ul = upd_list(smem);
     int* s_cass = reinterpret_cast<int*>(smem + l_cass);
     LdsStream rs{reinterpret_cast<const uint32_t*>(smem + L_RNG0), reinterpret_cast<const uint32_t*>(smem + L_RNG1),
-                 ctl[C_CURSOR], &ctl[C_RNGERR]};
-
-#ifdef GM_SWEEP_PROF
-    if (lane == 0) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[7] = __builtin_amdgcn_s_memrealtime();
-#endif
-    int cursor = rs.cursor;                      // wave-uniform: RNG words consumed so far
-    int run = 2 * nb;                            // markers walked, for the batch-size estimate
-    bool stopped = false, planned = false;
+                 w.cursor, &ctl[C_RNGERR]};
+    int cursor = w.cursor, run = w.run, nupd = w.nupd, ncross = w.ncross, from = w.from, ndone = w.ndone;
+    bool stopped = false, planned = false, repeek = w.repeek;
+    int part = from >> 6;
+    if (!HOT) {
+        // the walk goes on behind the marker the first piece stopped at: patch the sums of the markers behind it
+        const double nonas = nm1 + 1.0;
+        const __int128 cb = (__int128)w.ai * w.xs + (__int128)w.bi * (long long)nonas;
+        const long long x0 = (long long)__builtin_rint(lin0.mave * nonas), x1 = (long long)__builtin_rint(lin1.mave * nonas);
+        // the exchanged G values of this lane's two positions (packed: stop 0 in bits 0..23, stop 1 in bits 24..47), still
+        // in LDS where poll_totals left the batch's totals
+        const double* s_tot = reinterpret_cast<const double*>(smem + L_TOT);
+        long long ex0 = 0, ex1 = 0;
+        if (lane > ps0 && lane < nb) ex0 = (long long)s_tot[2 * nb + 2 + lane - ps0 - 1];
+        if (lane + 64 > ps0 && lane + 64 < nb) ex1 = (long long)s_tot[2 * nb + 2 + lane + 64 - ps0 - 1];
+        const long long g0 = w.q ? (ex0 >> 24) : (ex0 & 0xFFFFFFll), g1 = w.q ? (ex1 >> 24) : (ex1 & 0xFFFFFFll);
+        if (lane > w.at) {
+            exact_split(exact_sum(tq0.t0, tq0.t1) + ((__int128)w.ai * g0 + (__int128)w.bi * x0), tq0.t0, tq0.t1);
+            exact_split(exact_sum(tq0.t2, tq0.t3) + cb, tq0.t2, tq0.t3);
+        }
+        if (lane + 64 > w.at) {
+            exact_split(exact_sum(tq1.t0, tq1.t1) + ((__int128)w.ai * g1 + (__int128)w.bi * x1), tq1.t0, tq1.t1);
+            exact_split(exact_sum(tq1.t2, tq1.t3) + cb, tq1.t2, tq1.t3);
+        }
+        ncross++;
+    }
+    w.q = -1;
 #pragma unroll 1
-    for (int part = 0; part < 2; part++) {                           // one copy of the code (instruction cache)
+    while (true) {                                                   // one copy of the code per piece (instruction cache)
         const int base = 64 * part;
-        if (stopped || base >= nb) break;
+        if (base >= nb) break;
         const int nbp = nb - base < 64 ? nb - base : 64;
+        const int lo = from > base ? from - base : 0;                // lanes below lo have been walked
         // field-wise selects between two register-resident sets (an indexed array would live in scratch)
         LaneIn in;
         in.m = part ? lin1.m : lin0.m; in.g = part ? lin1.g : lin0.g;
         in.beta_old = part ? lin1.beta_old : lin0.beta_old; in.mave = part ? lin1.mave : lin0.mave; in.msig = part ? lin1.msig : lin0.msig;
         Totals tt;
-        tt.t0 = part ? tot1.t0 : tot0.t0; tt.t1 = part ? tot1.t1 : tot0.t1; tt.t2 = part ? tot1.t2 : tot0.t2; tt.t3 = part ? tot1.t3 : tot0.t3;
-        const bool act = lane < nbp;
+        tt.t0 = part ? tq1.t0 : tq0.t0; tt.t1 = part ? tq1.t1 : tq0.t1; tt.t2 = part ? tq1.t2 : tq0.t2; tt.t3 = part ? tq1.t3 : tq0.t3;
+        const bool act = lane < nbp && lane >= lo;
         const int m = in.m, g = in.g;
         const double beta_old = in.beta_old;
         const LaneTab<K> tb = load_tab<K>(tab, G, g);
@@ -511,7 +589,8 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
         const unsigned long long use_mask = __ballot(use);
         const int prefix = __popcll(use_mask & ((1ull << lane) - 1ull));
         const int cursor0 = cursor;
-        const double prob = part ? draws.p1 : draws.p0;                  // bayes.cpp:435: word cursor0 + prefix of the stream (sample_prepare)
+        double prob = part ? draws.p1 : draws.p0;                        // bayes.cpp:435: word cursor0 + prefix of the stream (sample_prepare)
+        if (repeek) prob = unif_from_word(rs.peek(cursor0 + prefix));
 
         SSTAMP(0);   // inputs, RNG peek
         int kc = 0;
@@ -551,51 +630,120 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
                 atomicAdd(&s_cass[g * K + 0], 1);
             }
         }
-        if (s < nbp && lane == s) {                                      // the stopping marker
+        if (s >= nbp) {                                                  // nobody stopped: on to the next 64 positions
+            cursor = cursor0 + __popcll(use_mask);
+            from = base + 64;
+            part++;
+            continue;
+        }
+        // ---- the stopping marker (lane s)
+        int upd = 0, cur_s = 0;
+        double alpha_ = 0.0, beta_ = 0.0;
+        if (lane == s) {
             rs.cursor = cursor0 + prefix + 1;
             double beta_new = 0.0;
             if (kc > 0) beta_new = norm_lx(rs, muk_c, sigmae / denom_c, (TabLds)reinterpret_cast<const double*>(smem + L_ZNX));   // bayes.cpp:455
             const double dbeta = beta_old - beta_new;                    // bayes.cpp:479
-            int upd = 0;
             if (fabs(dbeta) > 0.0) {                                     // bayes.cpp:483, phenotype.cpp:328-329,388
                 upd = 1;
                 // (mdb * b + a) * bs_ per genotype on the residual's grid (gm_common.h: v(a) = beta_ + a * alpha_), indexed
                 // by the RING code c' (k_sweep, phase A): c' = a for a = 0, 1, 2 and 3 for a missing genotype
-                double alpha_, beta_;
                 update_values(dbeta, in.mave, in.msig, alpha_, beta_);
                 const double v1 = beta_ + alpha_;
-                s_val[0] = beta_;
-                s_val[1] = v1;
-                s_val[2] = v1 + alpha_;
-                s_val[3] = 0.0;
+                double* uv = ul.val + 4 * nupd;
+                uv[0] = beta_;
+                uv[1] = v1;
+                uv[2] = v1 + alpha_;
+                uv[3] = 0.0;
+                ul.pos[nupd] = base + s;
             }
             if (writer) {
                 out.acum[m] = acum_v; out.betas_out[m] = beta_new; out.comp[m] = kc;
                 atomicAdd(&s_cass[g * K + kc], 1);
             }
-            ctl[C_UPD] = upd;
-            ctl[C_SUPD] = base + s;
-            ctl[C_CURSOR] = rs.cursor;
-            ctl[C_NDONE] = base + n_done;
+            cur_s = rs.cursor;
         }
         SSTAMP(3);   // commit + stop lane
-        if (s < nbp) {
-            stopped = true;
-            run = base + s + 1;
-            // a stop at a marker with a non-zero effect was planned (the batch ends there by construction,
-            // see compute_publish): it says nothing about how long a batch may usefully be
-            planned = __builtin_amdgcn_readlane((int)(beta_old != 0.0), s) != 0;
+        upd = __builtin_amdgcn_readlane(upd, s);
+        cursor = __builtin_amdgcn_readlane(cur_s, s);
+        nupd += upd;
+        from = base + s + 1;
+        ndone = from;
+        repeek = true;
+        if (!upd) {                                                      // the draw left the effect as it was: nothing moved, walk on
+            if (from >= base + nbp) part++;
+            continue;
         }
-        else cursor = cursor0 + __popcll(use_mask);
+        const int q = !CONT ? -1 : ((ns > 0 && base + s == ps0) ? 0 : ((ns > 1 && base + s == ps1) ? 1 : -1));
+        if (CONT && q >= 0) {                                            // (uniform) one of the batch's markers the walk may cross
+            // |values| >= 2^10 would not fit the integers of the patch; they put the residual out of range anyway (error 4 in phase C)
+            const double al = readlane64(alpha_, s), be = readlane64(beta_, s);
+            if (fabs(al) < 1024.0 && fabs(be) < 1024.0) {
+                w.q = q; w.at = base + s;
+                w.ai = (long long)(al * GRID_INV); w.bi = (long long)(be * GRID_INV);
+                w.xs = (long long)__builtin_rint(readlane64(in.mave, s) * (nm1 + 1.0));
+                if (HOT) break;                                          // the continuation takes over
+                // (second piece) patch and walk on
+                const double nonas = nm1 + 1.0;
+                const __int128 cb = (__int128)w.ai * w.xs + (__int128)w.bi * (long long)nonas;
+                const long long x0 = (long long)__builtin_rint(lin0.mave * nonas), x1 = (long long)__builtin_rint(lin1.mave * nonas);
+                const double* s_tot = reinterpret_cast<const double*>(smem + L_TOT);
+                long long ex0 = 0, ex1 = 0;
+                if (lane > ps0 && lane < nb) ex0 = (long long)s_tot[2 * nb + 2 + lane - ps0 - 1];
+                if (lane + 64 > ps0 && lane + 64 < nb) ex1 = (long long)s_tot[2 * nb + 2 + lane + 64 - ps0 - 1];
+                const long long g0 = q ? (ex0 >> 24) : (ex0 & 0xFFFFFFll), g1 = q ? (ex1 >> 24) : (ex1 & 0xFFFFFFll);
+                if (lane > w.at) {
+                    exact_split(exact_sum(tq0.t0, tq0.t1) + ((__int128)w.ai * g0 + (__int128)w.bi * x0), tq0.t0, tq0.t1);
+                    exact_split(exact_sum(tq0.t2, tq0.t3) + cb, tq0.t2, tq0.t3);
+                }
+                if (lane + 64 > w.at) {
+                    exact_split(exact_sum(tq1.t0, tq1.t1) + ((__int128)w.ai * g1 + (__int128)w.bi * x1), tq1.t0, tq1.t1);
+                    exact_split(exact_sum(tq1.t2, tq1.t3) + cb, tq1.t2, tq1.t3);
+                }
+                ncross++;
+                w.q = -1;
+                if (from >= base + nbp) part++;
+                continue;
+            }
+        }
+        stopped = true;
+        run = base + s + 1;
+        // a stop at a marker with a non-zero effect was planned (the batch ends there by construction,
+        // see compute_publish): it says nothing about how long a batch may usefully be
+        planned = __builtin_amdgcn_readlane((int)(beta_old != 0.0), s) != 0;
+        break;
     }
-    if (!stopped && lane == 0) {
-        ctl[C_UPD] = 0;
-        ctl[C_CURSOR] = cursor;
-        ctl[C_NDONE] = nb;
+    w.cursor = cursor; w.run = run; w.nupd = nupd; w.ncross = ncross; w.from = from; w.ndone = ndone;
+    w.stopped = stopped; w.planned = planned; w.repeek = repeek;
+}
+
+template <int K, bool CONT, class TP>
+__device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
+                                                  const LaneIn& lin0, const LaneIn& lin1, Totals& tq0, Totals& tq1,
+                                                  const Draws draws, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass,
+                                                  int ns, int ps0, int ps1) {
+    const int lane = threadIdx.x & 63;
+    int* ctl = reinterpret_cast<int*>(smem + L_CTL);
+#ifdef GM_SWEEP_PROF
+    if (lane == 0) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[7] = __builtin_amdgcn_s_memrealtime();
+#endif
+    Walk w;
+    w.cursor = ctl[C_CURSOR]; w.run = 2 * nb; w.nupd = 0; w.ncross = 0; w.from = 0; w.ndone = nb;
+    w.stopped = false; w.planned = false; w.repeek = false; w.q = -1; w.at = 0; w.ai = 0; w.bi = 0; w.xs = 0;
+    walk_piece<K, CONT, true>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
+    if (CONT) {
+        if (w.q >= 0)                                                // (uniform) the walk met a marker it may cross
+            walk_piece<K, true, false>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
     }
-    if (lane == 0) ctl[C_PLN] = planned ? 1 : 0;
-    if (lane == 0 && !planned) {                                     // next batch size from the recent run length
-        const int ema = (3 * ctl[C_EMA] + 16 * run) / 4;            // fixed point, 1/16 marker
+    if (lane == 0) {
+        ctl[C_UPD] = w.nupd;
+        ctl[C_SUPD] = w.ncross;
+        ctl[C_CURSOR] = w.cursor;
+        ctl[C_NDONE] = w.stopped ? w.ndone : nb;
+        ctl[C_PLN] = w.planned ? 1 : 0;
+    }
+    if (lane == 0 && !w.planned) {                                   // next batch size from the recent run length
+        const int ema = (3 * ctl[C_EMA] + 16 * w.run) / 4;          // fixed point, 1/16 marker
         ctl[C_EMA] = ema;
         const int want = nbf16 * ema / 256;
         int nxt = 16;                                                // a power of two >= want: lanes are free up to it
@@ -605,11 +753,13 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
 }
 
 // K = 4 (the reference's example mixtures) is inlined into the kernel; other K share out-of-line copies.
-template <int K, class TP>
+template <int K, bool CONT, class TP>
 __device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
                                           const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
-                                          double p0, double p1, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass) {
-    sample_batch_body<K>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tot0, tot1, Draws{p0, p1}, sigmae, inv2sige, nm1, out, writer, l_cass);
+                                          double p0, double p1, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass,
+                                          int ns, int ps0, int ps1) {
+    Totals tq0 = tot0, tq1 = tot1;
+    sample_batch_body<K, CONT>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tq0, tq1, Draws{p0, p1}, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
 }
 
 // rank of batch position p among the dirty markers of the batch (dm0: positions 0..63, dm1: 64..127)
@@ -814,6 +964,26 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 template <int R, int MODE>
 __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     constexpr bool FAST = MODE == 0;
+#ifdef GM_NOCONT
+    constexpr bool CONT = false;
+#else
+    constexpr bool CONT = MODE == 0;                 // the walk may cross markers whose effect was non-zero (no missing genotypes anywhere in the block)
+#endif
+#ifdef GM_NOCONT_S
+    constexpr bool CONT_S = false;
+#else
+    constexpr bool CONT_S = CONT;
+#endif
+#ifdef GM_NOCONT_P
+    constexpr bool CONT_P = false;
+#else
+    constexpr bool CONT_P = CONT;
+#endif
+#ifdef GM_NOCONT_T
+    constexpr bool CONT_T = false;
+#else
+    constexpr bool CONT_T = CONT;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GE = Geo<R>;
     constexpr int NI = 4 * R;                        // individuals per thread
@@ -831,7 +1001,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // Otherwise the markers' flags decide per marker (2 more values) and per tile of 16 (a second MFMA set).
     const int BMAX = RPOS / 2;                       // cap of the batch-size estimate: two batches live in the ring (dirty markers shorten a batch: 2 more slots each)
 
-    const double* s_val = reinterpret_cast<const double*>(smem + L_UPD + 16);
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     uint32_t* s_rng0 = reinterpret_cast<uint32_t*>(smem + L_RNG0);
     uint32_t* s_rng1 = reinterpret_cast<uint32_t*>(smem + L_RNG1);
@@ -842,7 +1011,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     long long* s_zsp = reinterpret_cast<long long*>(smem + L_ZSP);
     double* s_tab = reinterpret_cast<double*>(smem + a.lds_tab);
     char* planes = smem + a.lds_pln;
-    const bool tab_in_lds = G * (1 + 3 * K) <= TAB_LDS;
     char* ring = smem + a.lds_ring;
     unsigned* abort_word = a.cnt + 64;
     const unsigned long long spin_limit = a.spin_ticks;
@@ -851,8 +1019,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 
     for (int i = tid; i < 624; i += SW_TPB) s_rng0[i] = a.rng_state[i];
     for (int i = tid; i < G * K; i += SW_TPB) s_cass[i] = 0;
-    if (tab_in_lds)
-        for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];
+    for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];
     for (int i = tid; i < SW_VMAX; i += SW_TPB) s_sum[i] = 0ull;
 #ifdef GM_SWEEP_PROF
     if (tid < 8) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[tid] = 0ull;
@@ -1108,9 +1275,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // the reducers); otherwise it is discarded and a fresh batch starts after the stopping
     // marker.  Generation g uses tag g+1 and buffer g&1; a buffer is rewritten only after every
     // workgroup has sampled the generation that used it.
-    struct Batch { int p0, nb, nv; unsigned gen; bool planned; unsigned long long dm0, dm1; };   // planned: ends at a marker known to stop the walk; dm: dirty positions
+    struct Batch { int p0, nb, nv; unsigned gen; bool planned; unsigned long long dm0, dm1; int ns, ps0, ps1; };   // planned: ends at a marker known to stop the walk; dm: dirty positions;
+                                                                                                                // ns, ps: the markers with a non-zero effect the walk may cross (batch positions)
     unsigned gen_next = 0;
-    long long n_upd = 0, n_batch = 0, n_disc = 0, n_planned = 0, n_stale = 0, n_fastb = 0;
+    long long n_upd = 0, n_batch = 0, n_disc = 0, n_planned = 0, n_stale = 0, n_fastb = 0, n_cross = 0;
     int max_nb = 0;
     bool ok = true;
 #ifdef GM_SWEEP_PROF
@@ -1164,16 +1332,37 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 if (fit < b.nb) b.nb = fit;           // fit >= 1
             }
         }
-        // A marker whose effect is non-zero always changes it (bayes.cpp:479-483: the new draw differs), so
-        // the walk is known to stop there: end the batch at the first such marker instead of computing dots
-        // behind it that are certain to go stale.  (Every wavefront scans the same LDS words: uniform.)
+        // A marker whose effect is non-zero always changes it (bayes.cpp:479-483: the new draw differs), so the walk is
+        // known to stop there.  Without continuation the batch ends at the first such marker (the dots behind it
+        // are certain to go stale); with it the walk crosses up to NSTOP of them -- their genotype values become planes
+        // of operand B below, so that the sums behind them can be patched exactly (sample_batch_body) -- and the batch
+        // ends at the next one.  (Every wavefront scans the same LDS words: uniform.)
         {
             const bool nz0 = lane < b.nb && rb0 != 0.0;
             const bool nz1 = lane + 64 < b.nb && rb1 != 0.0;
-            const unsigned long long m0 = __ballot(nz0), m1 = __ballot(nz1);
+            unsigned long long m0 = __ballot(nz0), m1 = __ballot(nz1);
             const int first = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : b.nb);
-            if (first + 1 < b.nb) b.nb = first + 1;
-            b.planned = first < b.nb;                 // the last marker of the batch has a non-zero effect
+            b.ns = 0; b.ps0 = 0; b.ps1 = 0;
+            // A crossing costs about half a round (the sums behind the marker are patched and decided again, its genotype values
+            // become a plane, more values are exchanged): it pays when a good part of the batch lies behind the marker
+            const int cross_thr = (b.nb * a.cross + 15) >> 4;   // a.cross: sixteenths of the batch (0: never)
+            if (CONT && a.cross && first + 1 < b.nb && first + cross_thr <= b.nb - 1) {   // (uniform)
+                auto pop_first = [&]() -> int {
+                    if (m0) { const int f = __ffsll((long long)m0) - 1; m0 &= m0 - 1ull; return f; }
+                    if (m1) { const int f = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1ull; return f; }
+                    return -1;
+                };
+                b.ns = 1; b.ps0 = pop_first();
+                int last = pop_first();                          // the stop that ends the batch, if any
+                if (NSTOP > 1 && last >= 0 && last + 1 < b.nb && last + cross_thr <= b.nb - 1) {
+                    b.ns = 2; b.ps1 = last; last = pop_first();
+                }
+                if (last >= 0 && last + 1 < b.nb) b.nb = last + 1;
+                b.planned = last >= 0;
+            } else {
+                if (first + 1 < b.nb) b.nb = first + 1;
+                b.planned = first < b.nb;                        // the last marker of the batch has a non-zero effect
+            }
         }
         const int nb = b.nb;
         if (!FAST) {                                  // keep the flags of the batch's positions only
@@ -1252,6 +1441,29 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 }
             }
         }
+        // The genotype values of the markers the walk may cross, as planes of operand B (columns 8, 9): a_s(i) for the
+        // phenotyped individuals, 0 for the others and for a missing genotype.  Every thread writes the bytes of its own
+        // individuals, from the marker's slice in the ring (as in phase C).
+        const int ns = b.ns, ps0 = b.ps0, ps1 = b.ps1;
+        if (CONT_P && ns > 0) {                         // (uniform)
+#pragma unroll 1
+            for (int q = 0; q < ns; q++) {
+                const int ps = p0 + (q ? ps1 : ps0);
+                const char* own = ring + (size_t)rmod(ps) * SB + 16 * (o_chunk ^ (ps & (CPP - 1))) + o_jb;
+                uint32_t pv[ND];
+#pragma unroll
+                for (int d = 0; d < ND; d++) {
+                    const uint32_t x = ((*reinterpret_cast<const uint32_t*>(own + 4 * d) | na_or[d]) >> (2 * o_fld)) & 0x03030303u;
+                    const uint32_t miss = x & (x >> 1) & 0x01010101u;            // ring code 3: missing genotype (or no phenotype)
+                    pv[d] = x & ~(miss | (miss << 1));
+                }
+                char* dst = planes + (7 + q) * PST + 64 + p0w;
+                if constexpr (ND == 1) *reinterpret_cast<uint32_t*>(dst) = pv[0];
+                else if constexpr (ND == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pv[0], pv[1]);
+                else *reinterpret_cast<uint4*>(dst) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
+            }
+            lds_barrier();
+        }
         // work split: nt tiles of 16 markers; the 4 wavefronts = tsplit tile groups x ksplit parts of the slice
         const int nt = (nb + 15) >> 4;
         const int tsplit = nt >= 4 ? 4 : (nt >= 2 ? 2 : 1);
@@ -1262,7 +1474,11 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // operand B: columns 0..6 = the digit planes, 8 and 9 = the planes of the markers the walk may cross; the others
         // (7, 10..15) read plane 0 and their results are dropped
         const int ncol = lane & 15;
+#ifdef GM_OLD_PBASE
+        const int poff = (ncol & 7) < 7 ? (ncol & 7) * PST + ((ncol & 7) >> 2) * 64 : 6 * PST + 64;
+#else
         const int poff = ncol < 7 ? ncol * PST + (ncol >> 2) * 64 : ((ncol == 8 || ncol == 9) ? (ncol - 1) * PST + 64 : 0);
+#endif
         const char* pbase = planes + poff + kg * 64;
         constexpr uint32_t M0 = 0x03030303u, M1 = 0x01010101u;
         // One pass = ONE or TWO tiles of 16 markers (t and t + tsplit: operand B is read once for both) x NS
@@ -1335,7 +1551,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 for (int r = 0; r < 4; r++) {
                     const int m = 16 * (t + q * tsplit) + 4 * kg + r;
                     const int xr = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);  // sum c' * digit (c' = a wherever the residual is not 0)
-                    const int x = n == 7 ? 0 : xr;                                      // the second part has three digits: column 7 is not a plane
+                    // columns 0..6: the digits of the two exact parts (the second has three: column 7 is not a plane)
+                    const int x = n == 7 ? 0 : xr;
                     const long long sx = quad_sum64((long long)x << (8 * (n & 3)));
                     if (TF) {
                         if ((n & 3) == 0 && n < 8 && m < nb) atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)sx);
@@ -1351,6 +1568,20 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                             if (all_dirty || dirty_at(dm0, dm1, m))
                                 atomicAdd(&s_sum[2 * nb + 2 + 2 * (all_dirty ? m : dirty_rank(dm0, dm1, m)) + (n >> 2)], (unsigned long long)(-sz));
                         }
+                    }
+                }
+            }
+            // columns 8, 9: G = sum a_j a_s over the slice for the markers s the walk may cross, kept for the markers behind s
+            // only and packed 24 bits apart in one slot (G < 2^24 over all individuals)
+            if (CONT_T && ns > 0) {                      // (uniform)
+#pragma unroll
+                for (int q = 0; q < NTL; q++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int m = 16 * (t + q * tsplit) + 4 * kg + r;
+                        const int xr = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);
+                        if (n == 8 && m > ps0 && m < nb) atomicAdd(&s_sum[2 * nb + 2 + m - ps0 - 1], (unsigned long long)xr);
+                        if (n == 9 && ns > 1 && m > ps1 && m < nb) atomicAdd(&s_sum[2 * nb + 2 + m - ps0 - 1], (unsigned long long)xr << 24);
                     }
                 }
             }
@@ -1380,8 +1611,16 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         PA(2);
         lds_barrier();                                // the LDS sums are complete (prefetches stay in flight)
         PA(3);
-        const int nv = 2 * nb + 2 + 2 * nd;
-        for (int vi = tid; vi < nv; vi += SW_TPB) {           // up to SW_VMAX values, 256 threads
+        const int nv0 = 2 * nb + 2 + 2 * nd;
+        const int nv = nv0 + ((CONT_T && ns > 0) ? nb - 1 - ps0 : 0);   // behind a crossed stop: one more value per marker
+        if (CONT_T && ns > 0) {                       // (uniform) packed G counts: integers < 2^48, exact as doubles
+            for (int vi = nv0 + tid; vi < nv; vi += SW_TPB) {
+                const double tot = (double)(long long)s_sum[vi];
+                s_sum[vi] = 0ull;
+                put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)vi * a.Wpad + wg), b.gen + 1u, tot);
+            }
+        }
+        for (int vi = tid; vi < nv0; vi += SW_TPB) {          // up to SW_VMAX values, 256 threads
             double tot;
             if (vi >= 2 * nb && vi < 2 * nb + 2) {  // sum q1, sum q2 over the slice
                 const int w2 = vi - 2 * nb;
@@ -1433,6 +1672,29 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 lds_barrier();
                 if (tid == 0) put_value(Tb + 2 * v, b.gen + 1u, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
                 lds_barrier();
+            } else if (rows == 2) {
+                // a batch with markers behind a crossed stop (or many dirty markers) has more rows than there are workgroups:
+                // rows wg and wg + W in one pass, both granules of a thread in flight together
+                double x0 = 0.0, x1 = 0.0;
+                if (tid < W) {
+                    Spin sp;
+                    sp.start(spin_limit);
+                    const unsigned long long* gp0 = Pb + 2 * ((size_t)wg * a.Wpad + tid);
+                    const unsigned long long* gp1 = Pb + 2 * ((size_t)(wg + W) * a.Wpad + tid);
+                    bool ok0 = false, ok1 = false;
+                    for (;;) {
+                        get_value2(gp0, gp1, b.gen + 1u, x0, ok0, x1, ok1);
+                        if (ok0 && ok1) break;
+                        if (sp.expired(abort_word)) { bad = true; x0 = 0.0; x1 = 0.0; break; }
+                    }
+                }
+                const double r2 = reduce2(x0, x1);            // lanes 0-31: sum of x0 over the wavefront, lanes 32-63: of x1 (exact values: any order)
+                if (lane == 0) s_red[wave] = r2;
+                if (lane == 32) s_red[4 + wave] = r2;
+                lds_barrier();
+                if (tid == 0) put_value(Tb + 2 * wg, b.gen + 1u, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+                if (tid == 64) put_value(Tb + 2 * (wg + W), b.gen + 1u, s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+                lds_barrier();
             } else {
                 // Fewer workgroups than rows (small N: 49 workgroups, up to 242 rows): all rows of this workgroup in ONE
                 // pass -- thread t waits for granules t, t + 256, ... of the rows x W it needs and adds each to its row's
@@ -1461,7 +1723,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         return bad;
     };
 
-    Batch cur{0, 0, 0, 0u, false, 0ull, 0ull}, nxt{0, 0, 0, 0u, false, 0ull, 0ull}, tb{0, 0, 0, 0u, false, 0ull, 0ull};
+    Batch cur{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0}, nxt{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0}, tb{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0};
     LaneIn li_cur0{0, 0, 0.0, 0.0, 1.0}, li_cur1{0, 0, 0.0, 0.0, 1.0}, li_nxt0{0, 0, 0.0, 0.0, 1.0}, li_nxt1{0, 0, 0.0, 0.0, 1.0};
     bool bad = false;
     {
@@ -1527,35 +1789,38 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
             Totals tot0{0.0, 0.0, 0.0, 0.0}, tot1{0.0, 0.0, 0.0, 0.0};
-            const Draws draws = tab_in_lds ? sample_prepare(cur.nb, smem, (TabLds)s_tab, li_cur0.g, li_cur1.g)
-                                           : sample_prepare(cur.nb, smem, (TabGlobal)a.sigmag, li_cur0.g, li_cur1.g);
+            const Draws draws = sample_prepare(cur.nb, smem, (TabLds)s_tab, li_cur0.g, li_cur1.g);
             const bool okw = poll_totals(cur.nb, cur.nv, cur.dm0, cur.dm1, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word, spin_limit);
             if (lane == 0) *reinterpret_cast<volatile int*>(&ctl[C_TOTF]) = (int)(cur.gen + 1u);   // the loaders may start
             TRACE(3);
             PROF(4);   // wait for the totals
             bad |= !okw;
             if (okw) {
-                // ONE copy of the step per table address space (only one of them runs in a launch)
+                // the tables are read through a pointer of known address space (LDS)
                 auto run_step = [&](auto tabq) {
+#ifdef GM_SAMPLER_OOL
+                    if (false) {
+#else
                     if (K == 4) {
-                        sample_batch_body<4>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, draws, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass);
+#endif
+                        sample_batch_body<4, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, draws, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1);
                     } else {
                         // out-of-line copies take their inputs by address: hand them copies, so that the
                         // loop-carried lane inputs themselves stay in registers (no scratch round trips)
                         const LaneIn lc0 = li_cur0, lc1 = li_cur1;
                         const Totals tc0 = tot0, tc1 = tot1;
                         switch (K) {
-                            case 2: sample_batch<2>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
-                            case 3: sample_batch<3>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
-                            case 5: sample_batch<5>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
-                            case 6: sample_batch<6>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
-                            case 7: sample_batch<7>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
-                            default: sample_batch<8>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass); break;
+                            case 4: sample_batch<4, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 2: sample_batch<2, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 3: sample_batch<3, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 5: sample_batch<5, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 6: sample_batch<6, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 7: sample_batch<7, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            default: sample_batch<8, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
                         }
                     }
                 };
-                if (tab_in_lds) run_step((TabLds)s_tab);
-                else run_step((TabGlobal)a.sigmag);
+                run_step((TabLds)s_tab);
             }
         }
         PROF(7);   // sampling step (wavefront 0's own time)
@@ -1573,20 +1838,27 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 
         // ---- phase C: residual update of the stopping marker (its slice is in the ring) ----
         const int n_done = ctl[C_NDONE];
-        const bool upd = ctl[C_UPD] != 0;
+        const int nupd = ctl[C_UPD];                  // residual updates of this round: the markers the walk crossed and the one it stopped at
+        const bool upd = nupd != 0;
         n_planned += ctl[C_PLN];
+        n_cross += ctl[C_SUPD];
         n_fastb += (cur.dm0 | cur.dm1) == 0ull ? 1 : 0;
         n_stale += cur.nb - n_done;                   // dots computed behind the stop: thrown away
         if (upd) {
-            n_upd++;
-            const int ps = pos + ctl[C_SUPD];
-            // this thread's ND dwords of the slice: field o_fld of each byte is one of its individuals (ring codes c')
-            const char* own = ring + (size_t)rmod(ps) * SB + 16 * (o_chunk ^ (ps & (CPP - 1))) + o_jb;
+            n_upd += nupd;
+            const UpdList ul = upd_list(smem);
+#pragma unroll 1
+            for (int u = 0; u < nupd; u++) {
+                const int ps = pos + ul.pos[u];
+                const double* uv = ul.val + 4 * u;
+                // this thread's ND dwords of the slice: field o_fld of each byte is one of its individuals (ring codes c')
+                const char* own = ring + (size_t)rmod(ps) * SB + 16 * (o_chunk ^ (ps & (CPP - 1))) + o_jb;
 #pragma unroll
-            for (int d = 0; d < ND; d++) {
-                const uint32_t cd = (*reinterpret_cast<const uint32_t*>(own + 4 * d) | na_or[d]) >> (2 * o_fld);
+                for (int d = 0; d < ND; d++) {
+                    const uint32_t cd = (*reinterpret_cast<const uint32_t*>(own + 4 * d) | na_or[d]) >> (2 * o_fld);
 #pragma unroll
-                for (int bb = 0; bb < 4; bb++) eps[4 * d + bb] += s_val[(cd >> (8 * bb)) & 3u];
+                    for (int bb = 0; bb < 4; bb++) eps[4 * d + bb] += uv[(cd >> (8 * bb)) & 3u];
+                }
             }
             refresh_planes();
         }
@@ -1630,7 +1902,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (tid == 0) {
             *a.rng_index = ctl[C_CURSOR];
             a.stats[0] = n_upd; a.stats[1] = n_batch; a.stats[2] = max_nb; a.stats[3] = n_disc;
-            a.stats[29] = n_planned; a.stats[30] = n_stale; a.stats[31] = n_fastb;
+            a.stats[29] = n_planned; a.stats[30] = n_stale; a.stats[31] = n_fastb; a.stats[32] = n_cross;
         }
     }
 #ifdef GM_SWEEP_PROF

@@ -167,6 +167,8 @@ typedef struct gmrm_sweep_out {
     long long n_stale_dots;    /* dot products computed behind a stop and thrown away        */
     long long n_fast_batches;  /* batches exchanged in the 2-value layout (all their markers */
                                /* free of missing genotypes among phenotyped individuals)    */
+    long long n_crossed_stops; /* residual updates the walk went past inside a round (the    */
+                               /* dot products behind them were patched exactly)             */
 } gmrm_sweep_out;
 
 /* Per-marker group labels (Bayes::group_index restricted to [S, S+M)), shared by all t. */
@@ -222,7 +224,7 @@ typedef struct gmrm_hyper {    /* one phenotype's state after an iteration      
     double pi_est[64 * GMRM_KMAX];
     long long n_updates, n_batches;
     double sweep_device_ms;
-    long long n_planned_stops, n_stale_dots, n_fast_batches;   /* see gmrm_sweep_out */
+    long long n_planned_stops, n_stale_dots, n_fast_batches, n_crossed_stops;   /* see gmrm_sweep_out */
 } gmrm_hyper;
 
 int gmrm_sampler_create(gmrm_sampler** out, gmrm_ctx* ctx, const gmrm_sampler_opts* opts);
