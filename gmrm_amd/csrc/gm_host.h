@@ -24,6 +24,7 @@ struct Trait {
     int nonas = 0;
     bool have_trait = false, have_stats = false, in_flight = false, empty = false;
     bool poisoned = false;          // a sweep failed inside the kernel: comp / acum partly written, sweeps refused until re-upload
+    long long in_model = 0;         // markers with a non-zero effect (betas[cur]): from the last sweep's component counts / gmrm_set_betas
     int miss_mode = 2;              // markers of the block with nomiss == 0: 0 none, 1 some, 2 all (or unknown)
     int G = 0, K = 0;
     // sweep workspace
@@ -60,6 +61,7 @@ struct gmrm_ctx {
     int max_resident_wg = 0;        // occupancy query x num_cu for the sweep kernel at this R
     int spin_timeout_ms = 4000;     // bound of every grid-wide wait inside the kernel (env GMRM_SPIN_TIMEOUT_MS)
     bool concurrent = true, have_bed = false, have_groups = false;
+    double cross_density = 0.01;    // launch the kernel that crosses stops when at least this fraction of the block's markers is in the model (env GMRM_CROSS_DENSITY)
     int cross_frac16 = 9;           // the walk crosses a marker with a non-zero effect when at least this many sixteenths of the batch lie behind it (env GMRM_CROSS_FRAC16)
     int batch_init = 16, nb_factor16 = 24, spec_factor16 = 64;   // sweep schedule knobs (env GMRM_NB_FACTOR16 / GMRM_SPEC_FACTOR16)
 };

@@ -675,7 +675,7 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, T
             continue;
         }
         const int q = !CONT ? -1 : ((ns > 0 && base + s == ps0) ? 0 : ((ns > 1 && base + s == ps1) ? 1 : -1));
-        if (CONT && q >= 0) {                                            // (uniform) one of the batch's markers the walk may cross
+        if (CONT && __builtin_expect(q >= 0, 0)) {                       // (uniform) one of the batch's markers the walk may cross
             // |values| >= 2^10 would not fit the integers of the patch; they put the residual out of range anyway (error 4 in phase C)
             const double al = readlane64(alpha_, s), be = readlane64(beta_, s);
             if (fabs(al) < 1024.0 && fabs(be) < 1024.0) {
@@ -732,7 +732,7 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
     w.stopped = false; w.planned = false; w.repeek = false; w.q = -1; w.at = 0; w.ai = 0; w.bi = 0; w.xs = 0;
     walk_piece<K, CONT, true>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
     if (CONT) {
-        if (w.q >= 0)                                                // (uniform) the walk met a marker it may cross
+        if (__builtin_expect(w.q >= 0, 0))                           // (uniform) the walk met a marker it may cross
             walk_piece<K, true, false>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
     }
     if (lane == 0) {
@@ -961,29 +961,13 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 
 // MODE: which markers of the block have a missing genotype among the phenotyped individuals ("dirty"; host: the
 // flags of the marker statistics) -- 0: none, 1: some (per-marker flags decide), 2: all.
-template <int R, int MODE>
+// CONT: the walk may cross markers whose effect was non-zero ("continuation", above; fast layout only).  A kernel of its own:
+// the code it adds costs the rounds that cross nothing ~3 % (register allocation), so the host launches it only for
+// sweeps in which enough markers are in the model for the crossings to pay (capi.cpp, gmrm_sweep_launch).
+template <int R, int MODE, bool CONT>
 __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
+    static_assert(!CONT || MODE == 0, "continuation: fast layout only");
     constexpr bool FAST = MODE == 0;
-#ifdef GM_NOCONT
-    constexpr bool CONT = false;
-#else
-    constexpr bool CONT = MODE == 0;                 // the walk may cross markers whose effect was non-zero (no missing genotypes anywhere in the block)
-#endif
-#ifdef GM_NOCONT_S
-    constexpr bool CONT_S = false;
-#else
-    constexpr bool CONT_S = CONT;
-#endif
-#ifdef GM_NOCONT_P
-    constexpr bool CONT_P = false;
-#else
-    constexpr bool CONT_P = CONT;
-#endif
-#ifdef GM_NOCONT_T
-    constexpr bool CONT_T = false;
-#else
-    constexpr bool CONT_T = CONT;
-#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GE = Geo<R>;
     constexpr int NI = 4 * R;                        // individuals per thread
@@ -1445,7 +1429,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // phenotyped individuals, 0 for the others and for a missing genotype.  Every thread writes the bytes of its own
         // individuals, from the marker's slice in the ring (as in phase C).
         const int ns = b.ns, ps0 = b.ps0, ps1 = b.ps1;
-        if (CONT_P && ns > 0) {                         // (uniform)
+        if (CONT && ns > 0) {                         // (uniform)
 #pragma unroll 1
             for (int q = 0; q < ns; q++) {
                 const int ps = p0 + (q ? ps1 : ps0);
@@ -1474,11 +1458,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // operand B: columns 0..6 = the digit planes, 8 and 9 = the planes of the markers the walk may cross; the others
         // (7, 10..15) read plane 0 and their results are dropped
         const int ncol = lane & 15;
-#ifdef GM_OLD_PBASE
-        const int poff = (ncol & 7) < 7 ? (ncol & 7) * PST + ((ncol & 7) >> 2) * 64 : 6 * PST + 64;
-#else
         const int poff = ncol < 7 ? ncol * PST + (ncol >> 2) * 64 : ((ncol == 8 || ncol == 9) ? (ncol - 1) * PST + 64 : 0);
-#endif
         const char* pbase = planes + poff + kg * 64;
         constexpr uint32_t M0 = 0x03030303u, M1 = 0x01010101u;
         // One pass = ONE or TWO tiles of 16 markers (t and t + tsplit: operand B is read once for both) x NS
@@ -1573,7 +1553,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             }
             // columns 8, 9: G = sum a_j a_s over the slice for the markers s the walk may cross, kept for the markers behind s
             // only and packed 24 bits apart in one slot (G < 2^24 over all individuals)
-            if (CONT_T && ns > 0) {                      // (uniform)
+            if (CONT && ns > 0) {                      // (uniform)
 #pragma unroll
                 for (int q = 0; q < NTL; q++) {
 #pragma unroll
@@ -1612,8 +1592,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         lds_barrier();                                // the LDS sums are complete (prefetches stay in flight)
         PA(3);
         const int nv0 = 2 * nb + 2 + 2 * nd;
-        const int nv = nv0 + ((CONT_T && ns > 0) ? nb - 1 - ps0 : 0);   // behind a crossed stop: one more value per marker
-        if (CONT_T && ns > 0) {                       // (uniform) packed G counts: integers < 2^48, exact as doubles
+        const int nv = nv0 + ((CONT && ns > 0) ? nb - 1 - ps0 : 0);   // behind a crossed stop: one more value per marker
+        if (CONT && ns > 0) {                       // (uniform) packed G counts: integers < 2^48, exact as doubles
             for (int vi = nv0 + tid; vi < nv; vi += SW_TPB) {
                 const double tot = (double)(long long)s_sum[vi];
                 s_sum[vi] = 0ull;
@@ -1798,25 +1778,20 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             if (okw) {
                 // the tables are read through a pointer of known address space (LDS)
                 auto run_step = [&](auto tabq) {
-#ifdef GM_SAMPLER_OOL
-                    if (false) {
-#else
                     if (K == 4) {
-#endif
-                        sample_batch_body<4, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, draws, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1);
+                        sample_batch_body<4, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, draws, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1);
                     } else {
                         // out-of-line copies take their inputs by address: hand them copies, so that the
                         // loop-carried lane inputs themselves stay in registers (no scratch round trips)
                         const LaneIn lc0 = li_cur0, lc1 = li_cur1;
                         const Totals tc0 = tot0, tc1 = tot1;
                         switch (K) {
-                            case 4: sample_batch<4, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 2: sample_batch<2, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 3: sample_batch<3, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 5: sample_batch<5, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 6: sample_batch<6, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 7: sample_batch<7, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            default: sample_batch<8, CONT_S>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 2: sample_batch<2, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 3: sample_batch<3, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 5: sample_batch<5, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 6: sample_batch<6, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 7: sample_batch<7, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            default: sample_batch<8, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
                         }
                     }
                 };
@@ -1925,22 +1900,22 @@ int sweep_pick_R(size_t stride, int max_wg, int* W_out) {
     return -1;
 }
 
-template <int R, int MODE> static hipError_t launch_RF(const SweepArgs& a0, hipStream_t st, int grid) {
+template <int R, int MODE, bool CONT> static hipError_t launch_RF(const SweepArgs& a0, hipStream_t st, int grid) {
     const int lds = lds_total<R>();
     SweepArgs a = a0;
     const Carve cv = carve_for<R>(a.G, a.K);
     a.lds_cass = cv.cass; a.lds_tab = cv.tab; a.lds_pln = cv.pln; a.lds_ring = cv.ring; a.rpos = cv.rpos; a.rpos_magic = cv.magic;
     if (cv.rpos < 32) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, MODE, CONT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_sweep<R, MODE>), dim3(grid), dim3(SW_TPB), lds, st, a);
+    hipLaunchKernelGGL((k_sweep<R, MODE, CONT>), dim3(grid), dim3(SW_TPB), lds, st, a);
     return hipGetLastError();
 }
 template <int R> static hipError_t launch_R(const SweepArgs& a, hipStream_t st, int grid) {
     switch (a.miss_mode) {
-        case 0: return launch_RF<R, 0>(a, st, grid);
-        case 2: return launch_RF<R, 2>(a, st, grid);
-        default: return launch_RF<R, 1>(a, st, grid);
+        case 0: return a.cross > 0 ? launch_RF<R, 0, true>(a, st, grid) : launch_RF<R, 0, false>(a, st, grid);
+        case 2: return launch_RF<R, 2, false>(a, st, grid);
+        default: return launch_RF<R, 1, false>(a, st, grid);
     }
 }
 
@@ -1961,13 +1936,13 @@ hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) {
 template <int R> static hipError_t occupancy_R(int* out) {
     const int lds = lds_total<R>();
     int n0 = 0, n1 = 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_sweep<R, 0>, SW_TPB, (size_t)lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_sweep<R, 0, true>, SW_TPB, (size_t)lds);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_sweep<R, 1>, SW_TPB, (size_t)lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_sweep<R, 1, false>, SW_TPB, (size_t)lds);
     if (e != hipSuccess) return e;
     *out = n0 < n1 ? n0 : n1;
     return hipSuccess;

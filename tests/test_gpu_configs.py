@@ -169,7 +169,10 @@ def test_full_size_chain_keeps_its_invariant(gpu, name, na_rate, miss_rate, G, d
             comp, betas = ctx.comp(0), ctx.betas(0)
             counts = np.bincount(comp, minlength=4)
             assert counts.sum() == M and int((betas != 0.0).sum()) == M - counts[0] == hy.m0_sum, name
-            assert hy.n_batches >= hy.n_updates and 0.1 < hy.sigmae < 2.0
+            # a round ends at a residual update unless the walk crosses it (markers that were in the model, fast layout only)
+            assert hy.n_batches >= hy.n_updates - hy.n_crossed_stops and 0.1 < hy.sigmae < 2.0
+            if name == "c3" and it >= 2:
+                assert hy.n_crossed_stops > 0                                    # sweeps 2, 3: ~8 % of the markers in the model
             if dirty:
                 assert 0 < hy.n_fast_batches < hy.n_batches                      # clean and mixed batches both occur
             g = ctx.predict_g(0, betas)

@@ -37,7 +37,7 @@ def agprs(text):
 def kernels(asm):
     cur, name = None, None
     for ln in asm.splitlines():
-        m = re.match(r"^(_ZN2gm7k_sweepILi\d+EL[bi]\d+EEEvNS_9SweepArgsE):", ln)
+        m = re.match(r"^(_ZN2gm7k_sweepILi\d+ELi\d+ELb[01]EEEvNS_9SweepArgsE):", ln)
         if m:
             name, cur = m.group(1), []
             continue
