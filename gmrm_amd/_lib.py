@@ -104,6 +104,7 @@ SIGNATURES = {
     "gmrm_sampler_save": (C.c_int, [VP, C.c_char_p, C.c_int]),
     "gmrm_sampler_load": (C.c_int, [VP, C.c_char_p, c_int_p]),
     "gmrm_selftest_math": (C.c_int, [C.c_int, C.c_int, c_double_p, c_double_p, C.c_int]),
+    "gmrm_selftest_shuffle": (C.c_int, [C.c_uint32, C.c_int, c_int_p]),
     "gmrm_eps_snapshot": (C.c_int, [VP, C.c_int]),
     "gmrm_eps_delta_export": (C.c_int, [VP, C.c_int, VP]),
     "gmrm_eps_delta_import": (C.c_int, [VP, C.c_int, VP]),

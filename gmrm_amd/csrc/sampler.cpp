@@ -54,6 +54,15 @@ using gm::fail;
 
 extern "C" {
 
+int gmrm_selftest_shuffle(uint32_t seed, int n, int* v) {
+    if (!v || n < 0) return gm::fail(GMRM_EINVAL, "bad argument");
+    gm::Mt19937 e;
+    e.seed(seed);
+    for (int i = 0; i < n; i++) v[i] = i;
+    gm::shuffle(e, v, n);
+    return GMRM_OK;
+}
+
 int gmrm_sampler_create(gmrm_sampler** out, gmrm_ctx* ctx, const gmrm_sampler_opts* o) {
     if (!out || !ctx || !o || !o->cva || !o->group_index) return fail(GMRM_EINVAL, "null argument");
     *out = nullptr;

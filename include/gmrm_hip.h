@@ -201,6 +201,10 @@ int gmrm_eps_delta_import(gmrm_ctx* ctx, int t, const double* dev_q);/* eps = st
  *   op 4: y[2i], y[2i+1] = split2(x[i])  (y holds 2n doubles)
  * ---------------------------------------------------------------------------------- */
 int gmrm_selftest_math(int device, int op, const double* x, double* y, int n);
+/* The marker shuffle of Phenotype::shuffle_midx (src/phenotype.cpp:314-323) as the host sampler performs it: v = 0..n-1
+ * shuffled with an mt19937 seeded `seed` (host only, no device needed).  tests/ hold it to permutations produced by
+ * libstdc++'s own std::random_shuffle + std::mt19937 (tests/golden/stl_shuffle.txt.gz). */
+int gmrm_selftest_shuffle(uint32_t seed, int n, int* v);
 
 /* ------------------------------------------------------------------------------------
  * Host-side sampler: Bayes::process() around the marker loop (src/bayes.cpp:318-371,

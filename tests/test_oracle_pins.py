@@ -259,6 +259,43 @@ def test_multi_rank_schedules_reproduce_their_fixture():
         assert b"".join(h["csv"]) == z[f"{sched}_csv"].tobytes(), sched
 
 
+def _stl_shuffle_fixture():
+    import gzip
+    out = []
+    for ln in gzip.open(GOLD / "stl_shuffle.txt.gz", "rt"):
+        head, perm = ln.split(":")
+        n, seed = (int(x) for x in head.split())
+        out.append((n, seed, np.array(perm.split(), dtype=np.int32)))
+    return out
+
+
+def test_shuffle_matches_libstdcxx_random_shuffle():
+    """Phenotype::shuffle_midx (src/phenotype.cpp:314-323) = boost::range::random_shuffle = std::random_shuffle(first, last,
+    rand) driven by an mt19937.  tests/golden/stl_shuffle.txt.gz holds the permutations libstdc++'s own std::random_shuffle
+    and std::mt19937 produce (oracle/ref_harness/stl_shuffle.cpp, generator = the restated uniform_int rule; Boost itself is
+    absent): the oracle's restatement of the loop and of the engine must give the same permutations, n = 2, 3, 777, 20000."""
+    L = orc.lib()
+    fx = _stl_shuffle_fixture()
+    assert len(fx) == 12 and {n for n, _, _ in fx} == {2, 3, 777, 20000}
+    for n, seed, want in fx:
+        assert sorted(want.tolist()) == list(range(n))
+        r = orc.OrcRng()
+        L.orc_rng_seed(C.byref(r), seed)
+        v = np.arange(n, dtype=np.int32)
+        L.orc_rng_shuffle(C.byref(r), v.ctypes.data_as(orc.c_int_p), n)
+        assert np.array_equal(v, want), (n, seed)
+
+
+def test_product_shuffle_matches_libstdcxx_random_shuffle():
+    """The same fixture against the product's host shuffle (gm_rng.h gm::shuffle through gmrm_selftest_shuffle; host code, no GPU)."""
+    import gmrm_amd
+    lib = gmrm_amd.load_library()
+    for n, seed, want in _stl_shuffle_fixture():
+        v = np.zeros(n, dtype=np.int32)
+        assert lib.gmrm_selftest_shuffle(seed, n, v.ctypes.data_as(orc.c_int_p)) == 0
+        assert np.array_equal(v, want), (n, seed)
+
+
 def test_predict_restatement_against_numpy():
     """Bayes::predict's loops (bayes.cpp:93-122, 172-205, 233-234) as restated in the oracle, checked
     against a direct numpy evaluation of the same formulas on decoded genotypes (no GPU)."""

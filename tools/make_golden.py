@@ -11,6 +11,8 @@
                        path against committed numbers.
   shards_k3_3ranks.npz case k3 on 3 ranks under the oracle's two multi-rank schedules (one exchange per sweep;
                        the reference's exchange per marker step).
+  stl_shuffle.txt.gz   permutations of libstdc++'s std::random_shuffle driven by std::mt19937 (the library code the
+                       reference's boost::range::random_shuffle ends in) for n in {2, 3, 777, 20000} x 3 seeds.
 Fixtures are data only: no reference source text is stored.
 """
 import os
@@ -54,6 +56,20 @@ def ref_parts():
         print(ext, (GOLD / f"ref_xfiles.{ext}").stat().st_size, "bytes")
 
 
+def stl_parts():
+    """tests/golden/stl_shuffle.txt.gz: permutations from libstdc++'s std::random_shuffle + std::mt19937 (oracle/ref_harness/stl_shuffle.cpp)."""
+    subprocess.run(["make", "-s", "-C", str(ROOT / "oracle"), "stl"], check=True)
+    args = []
+    for n in (2, 3, 777, 20000):
+        for seed in (0, 171014, 4294967295):
+            args += [str(n), str(seed)]
+    out = subprocess.run([str(ROOT / "oracle/_build/stl_shuffle"), *args], check=True, capture_output=True, text=True).stdout
+    import gzip
+    with gzip.GzipFile(GOLD / "stl_shuffle.txt.gz", "wb", mtime=0) as f:
+        f.write(out.encode())
+    print("stl_shuffle.txt.gz", len(out), "bytes of text")
+
+
 def chain_parts():
     from tests import cases
     cases.write_golden(GOLD)
@@ -62,8 +78,10 @@ def chain_parts():
 
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
-    what = sys.argv[1:] or ["ref", "chains"]
+    what = sys.argv[1:] or ["ref", "chains", "stl"]
     if "ref" in what:
         ref_parts()
     if "chains" in what:
         chain_parts()
+    if "stl" in what:
+        stl_parts()
