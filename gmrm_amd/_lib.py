@@ -114,11 +114,14 @@ SIGNATURES = {
     "gmrm_sampler_iterate": (C.c_int, [VP, C.c_int]),
     "gmrm_sampler_draw_mu": (C.c_int, [VP, C.c_int, c_double_p]),
     "gmrm_sampler_begin_sweep": (C.c_int, [VP, c_double_p]),
+    "gmrm_sampler_launch_sweep": (C.c_int, [VP, c_double_p]),
+    "gmrm_sampler_preshuffle": (C.c_int, [VP]),
     "gmrm_sampler_end_sweep": (C.c_int, [VP, c_int_p, c_double_p]),
     "gmrm_sampler_epilogue": (C.c_int, [VP, c_int_p, c_double_p]),
     "gmrm_sampler_begin_steps": (C.c_int, [VP, c_double_p]),
     "gmrm_sampler_step": (C.c_int, [VP, C.c_int, c_int_p, c_double_p]),
     "gmrm_sampler_end_steps": (C.c_int, [VP, c_int_p, c_double_p]),
+    "gmrm_sampler_abort_steps": (C.c_int, [VP]),
     "gmrm_sampler_adopt": (C.c_int, [VP, C.c_int, c_double_p, c_double_p, C.c_double]),
     "gmrm_sampler_get": (C.c_int, [VP, C.c_int, C.POINTER(HyperC)]),
     "gmrm_sampler_csv_line": (C.c_int, [VP, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),

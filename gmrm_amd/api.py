@@ -335,6 +335,10 @@ class Sampler:
         check(self.lib.gmrm_sampler_step(self.h, int(mrki), C.byref(mloc), _dp(d3)))
         return mloc.value, d3
 
+    def abort_steps(self):
+        """Leave a per-step sweep that cannot be completed (gmrm_sampler_abort_steps)."""
+        check(self.lib.gmrm_sampler_abort_steps(self.h))
+
     def end_steps(self):
         T = self.ctx.T
         cass = np.zeros((T, self.G, self.K), dtype=np.int32)

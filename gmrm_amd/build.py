@@ -17,7 +17,7 @@ HEADERS = ["gm_common.h", "gm_rng.h", "gm_internal.h", "gm_host.h", "zig_tables.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall",
          "-Wno-unused-function"]
 # host-only translation units: plain C++ against the HIP runtime API (no device pass)
-HOST_FLAGS = ["-O2", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-fPIC", "-std=c++17", "-Wall",
+HOST_FLAGS = ["-O2", "-pthread", "-ffp-contract=off", "-fno-fast-math", "-mfma", "-fPIC", "-std=c++17", "-Wall",
               "-Wno-unused-function", "-Wno-unused-result", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
 
 
@@ -74,7 +74,7 @@ def _build(force: bool, verbose: bool, objname: str) -> Path:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", str(LIB), *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")

@@ -7,6 +7,9 @@
 #include "gm_host.h"
 
 #include <hip/hip_runtime.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -41,14 +44,40 @@ struct InFlight { const gmrm_ctx* ctx; int t; hipStream_t stream; int wgs; };
 static std::mutex g_dev_mu;
 static std::map<int, std::vector<InFlight>> g_dev_inflight;
 
-static int device_inflight_wgs(int device, const gmrm_ctx* c) {
+static int device_inflight_wgs(int device, const gmrm_ctx* c, int own_extra) {
     // a context runs at most `conc` of its own launches at once (the others queue behind them on the
     // same streams); other contexts' launches are counted in full
-    int own = 0, others = 0;
+    int own = own_extra, others = 0;
     for (const InFlight& f : g_dev_inflight[device]) {
         if (f.ctx == c) own++; else others += f.wgs;
     }
     return others + std::min(own, c->conc) * c->W;
+}
+
+// The bookkeeping above is per PROCESS.  Two processes that sweep on one device cannot see each other's grids; if the
+// two could not be co-resident (each needs more than half of the device's resident workgroups) their workgroups would
+// interleave and both sweeps would end in the spin timeout.  Such sweeps therefore hold an advisory lock on a per-device
+// file from launch to finish (flock: released by the kernel if the process dies), so that they alternate instead.  One
+// descriptor per device and process, counted: contexts of one process share it (they are ordered by the bookkeeping above).
+struct DevLock { int fd = -1; int holders = 0; };
+static std::map<int, DevLock> g_dev_lock;                     // guarded by g_dev_mu
+
+static void devlock_acquire(int device) {                     // g_dev_mu held
+    DevLock& L = g_dev_lock[device];
+    if (L.holders++ > 0) return;
+    if (L.fd < 0) {
+        char bus[64] = "unknown";
+        (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device);
+        for (char* p = bus; *p; p++) if (*p == ':' || *p == '.' || *p == '/') *p = '_';
+        const char* dir = std::getenv("GMRM_LOCK_DIR");
+        const std::string path = std::string(dir ? dir : "/tmp") + "/gmrm_hip_" + bus + ".lock";
+        L.fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    }
+    if (L.fd >= 0) (void)::flock(L.fd, LOCK_EX);              // may wait for another process's sweep; no lock file, no guard
+}
+static void devlock_release(int device) {                     // g_dev_mu held
+    DevLock& L = g_dev_lock[device];
+    if (L.holders > 0 && --L.holders == 0 && L.fd >= 0) (void)::flock(L.fd, LOCK_UN);
 }
 
 int ctx_check_t(const gmrm_ctx* c, int t) {
@@ -200,6 +229,8 @@ int gmrm_ctx_destroy(gmrm_ctx* c) {
         std::lock_guard<std::mutex> lk(g_dev_mu);
         auto& v = g_dev_inflight[c->device];
         v.erase(std::remove_if(v.begin(), v.end(), [&](const InFlight& f) { return f.ctx == c; }), v.end());
+        for (auto& tr : c->tr)
+            if (tr.holds_devlock) { devlock_release(c->device); tr.holds_devlock = false; }
     }
     for (auto& tr : c->tr) {
         if (tr.stream) hipStreamSynchronize(tr.stream);
@@ -635,28 +666,36 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     // Phenotypes that do not fit side by side share stream 0 and run one after another.
     hipStream_t st = c->tr[t % c->conc].stream;       // conc chains side by side, the others queue behind them
     if (t % c->conc != t) HIPCHK(hipStreamSynchronize(tr.stream));           // uploads above done
-    // Co-residency across contexts that share this device: wait for sweeps that would not fit beside this one.
-    {
-        std::unique_lock<std::mutex> lk(g_dev_mu);
-        auto& v = g_dev_inflight[c->device];
-        v.push_back(InFlight{c, t, st, c->W});
-        while (device_inflight_wgs(c->device, c) > c->max_resident_wg) {
-            auto it = std::find_if(v.begin(), v.end(), [&](const InFlight& f) { return f.ctx != c; });
-            if (it == v.end()) break;                   // only this context's own launches: they queue on its streams
-            const hipStream_t other = it->stream;
-            v.erase(it);                                // its owner's gmrm_sweep_finish still synchronises the stream
-            lk.unlock();
-            HIPCHK(hipStreamSynchronize(other));
-            lk.lock();
-        }
-    }
+    // Co-residency across contexts that share this device: wait for sweeps that would not fit beside this one.  The
+    // mutex is held from the check to the enqueue, so that an entry becomes visible together with its kernel (two host
+    // threads launching on one device cannot both see "room"), and nothing is registered when the launch fails.
     int grid = c->W;
     if (const char* e = std::getenv("GMRM_FAULT_DROP_WG")) {                 // test hook: launch one workgroup short, so the
         if (std::atoi(e) > 0 && grid > 1) grid -= 1;                         // grid-wide wait can never complete (timeout path)
     }
-    HIPCHK(hipEventRecord(tr.ev0, st));
-    HIPCHK(launch_sweep(a, c->R, st, grid));
-    HIPCHK(hipEventRecord(tr.ev1, st));
+    {
+        std::unique_lock<std::mutex> lk(g_dev_mu);
+        auto& v = g_dev_inflight[c->device];
+        while (device_inflight_wgs(c->device, c, 1) > c->max_resident_wg) {
+            auto it = std::find_if(v.begin(), v.end(), [&](const InFlight& f) { return f.ctx != c; });
+            if (it == v.end()) break;                   // only this context's own launches: they queue on its streams
+            const hipStream_t other = it->stream;
+            v.erase(it);                                // its owner's gmrm_sweep_finish still synchronises the stream
+            HIPCHK(hipStreamSynchronize(other));        // (the kernel it waits for needs nothing from this host thread)
+        }
+        // another PROCESS on this device: see devlock_acquire
+        const bool exclusive = 2 * c->W * c->conc > c->max_resident_wg && !std::getenv("GMRM_NO_DEVICE_LOCK");
+        if (exclusive) devlock_acquire(c->device);
+        hipError_t le = hipEventRecord(tr.ev0, st);
+        if (le == hipSuccess) le = launch_sweep(a, c->R, st, grid);
+        if (le == hipSuccess) le = hipEventRecord(tr.ev1, st);
+        if (le != hipSuccess) {
+            if (exclusive) devlock_release(c->device);
+            return hip_fail(le, "sweep launch");
+        }
+        tr.holds_devlock = exclusive;
+        v.push_back(InFlight{c, t, st, c->W});
+    }
     tr.launch_stream = st;
     tr.in_flight = true;
     return GMRM_OK;
@@ -673,13 +712,15 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
         return GMRM_OK;
     }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(tr.launch_stream));
+    const hipError_t sync_err = hipStreamSynchronize(tr.launch_stream);
     {
         std::lock_guard<std::mutex> lk(g_dev_mu);
         auto& v = g_dev_inflight[c->device];
         auto it = std::find_if(v.begin(), v.end(), [&](const InFlight& f) { return f.ctx == c && f.t == t; });
         if (it != v.end()) v.erase(it);
+        if (tr.holds_devlock) { devlock_release(c->device); tr.holds_devlock = false; }
     }
+    if (sync_err != hipSuccess) { tr.poisoned = true; return hip_fail(sync_err, "hipStreamSynchronize(sweep)"); }
     int err[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(err, tr.err, sizeof(err), hipMemcpyDeviceToHost));
     if (err[0] != 0) {

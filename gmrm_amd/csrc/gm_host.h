@@ -23,6 +23,7 @@ struct Trait {
     double* acum = nullptr;         // Phenotype::acum [M]
     int nonas = 0;
     bool have_trait = false, have_stats = false, in_flight = false, empty = false;
+    bool holds_devlock = false;     // this sweep holds the per-device advisory lock against other processes (capi.cpp)
     bool poisoned = false;          // a sweep failed inside the kernel: comp / acum partly written, sweeps refused until re-upload
     long long in_model = 0;         // markers with a non-zero effect (betas[cur]): from the last sweep's component counts / gmrm_set_betas
     int miss_mode = 2;              // markers of the block with nomiss == 0: 0 none, 1 some, 2 all (or unknown)

@@ -401,9 +401,12 @@ constexpr int AS_PLN = 8 * AS_PST + 64;
 constexpr int AS_MW = 32, AS_MB = 4 * AS_MW;      // markers per wavefront / per workgroup
 typedef int as_v4i __attribute__((ext_vector_type(4)));
 
-__global__ void k_absmax(const double* __restrict__ y, size_t n, unsigned long long* __restrict__ out) {
+__global__ void k_absmax(const double* __restrict__ y, const uint8_t* __restrict__ namask2, size_t n, unsigned long long* __restrict__ out) {
     unsigned long long m = 0ull;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        // individuals without a phenotype do not enter the sums (k_yplanes gives them zero planes): whatever y holds for
+        // them -- NaN included -- must not set the scale
+        if (((namask2[i >> 2] >> (2 * (i & 3))) & 3u) != 3u) continue;
         const unsigned long long b = (unsigned long long)__double_as_longlong(fabs(y[i]));
         m = b > m ? b : m;                         // |y| as bits: monotone for finite values; NaN / Inf end up on top
     }
@@ -482,6 +485,18 @@ __global__ __launch_bounds__(256) void k_assoc_mfma(const uint8_t* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 2; q++) { acc0[q] = as_v4i{0, 0, 0, 0}; acc1[q] = as_v4i{0, 0, 0, 0}; acc2[q] = as_v4i{0, 0, 0, 0}; }
     int n1[2] = {0, 0}, n2[2] = {0, 0};
+    // An int32 accumulator takes up to 2^21 per block (512 individuals of one field x 32 x 128): it is folded into a 64-bit
+    // total every AS_FOLD blocks, far below 2^31 (the run over a whole column of 2^22 individuals could reach it)
+    constexpr int AS_FOLD = 256;
+    long long tx[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    auto fold = [&]() {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) tx[q][r] += (long long)(acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4));
+            acc0[q] = as_v4i{0, 0, 0, 0}; acc1[q] = as_v4i{0, 0, 0, 0}; acc2[q] = as_v4i{0, 0, 0, 0};
+        }
+    };
     constexpr uint32_t M0 = 0x03030303u, LO = 0x55555555u;
     // a rolling window of AS_SS super-steps of column chunks: a chunk is requested again (for the next block) as soon
     // as it has been used, so that a block's worth of loads is always in flight
@@ -542,7 +557,9 @@ __global__ __launch_bounds__(256) void k_assoc_mfma(const uint8_t* __restrict__ 
             for (int n = 0; n < 8; n++) *reinterpret_cast<pbt*>(s_pl[par ^ 1] + n * AS_PST + (n >> 2) * 64 + PBB * tid) = pb[n];
             if (tid < AS_BLK / 16) s_nm[par ^ 1][tid] = pn;
         }
+        if ((blk & (AS_FOLD - 1)) == AS_FOLD - 1) fold();
     }
+    fold();
     // C: column n = lane & 15 (digit plane n < 8), rows 4 kg + r (marker of the tile); the four planes of a part meet in a quad
     const int n = lane & 15;
     const int sh = assoc_shift(*maxbits);
@@ -557,8 +574,7 @@ __global__ __launch_bounds__(256) void k_assoc_mfma(const uint8_t* __restrict__ 
         if (kg == 0 && mq < M) xtx[mq] = (double)((long long)c1 + 4ll * (long long)c2);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int x = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);
-            long long sx = (long long)x << (8 * (n & 3));
+            long long sx = tx[q][r] << (8 * (n & 3));
             sx += ((long long)__shfl_xor((int)(sx >> 32), 1, 64) << 32) + (long long)(unsigned)__shfl_xor((int)sx, 1, 64);
             sx += ((long long)__shfl_xor((int)(sx >> 32), 2, 64) << 32) + (long long)(unsigned)__shfl_xor((int)sx, 2, 64);
             // lanes n = 0..3 hold the sum of part 1 (units of 2^-22), n = 4..7 of part 2 (units of 2^-53)
@@ -615,7 +631,7 @@ hipError_t launch_assoc(const uint8_t* bed, const uint8_t* namask2, size_t strid
     unsigned long long* maxbits = reinterpret_cast<unsigned long long*>(planes + 8 * npad);
     hipError_t e = hipMemsetAsync(maxbits, 0, sizeof(unsigned long long), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, y, 4 * stride, maxbits);
+    hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, y, namask2, 4 * stride, maxbits);
     hipLaunchKernelGGL(k_yplanes, dim3((unsigned)((npad / 4 + 255) / 256)), dim3(256), 0, st, y, namask2, stride, maxbits, planes, npad);
     hipLaunchKernelGGL(k_assoc_mfma, dim3((unsigned)((M + AS_MB - 1) / AS_MB)), dim3(256), 0, st, bed, namask2, stride, M,
                        planes, npad, maxbits, xtx, xty);

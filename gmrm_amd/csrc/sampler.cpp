@@ -129,6 +129,16 @@ int gmrm_sampler_init(gmrm_sampler* s) {
     return GMRM_OK;
 }
 
+// A per-step sweep is open (gmrm_sampler_begin_steps .. _end_steps: the device's effects / components are stale against
+// the host copies, the residual is offset by -mu) or a kernel sweep is in flight: the chain state cannot be read or replaced.
+static const char* busy_reason(const gmrm_sampler* s) {
+    for (int t = 0; t < s->ctx->T; t++) {
+        if (s->ch[t].stepping) return "a per-step sweep is open (gmrm_sampler_end_steps or gmrm_sampler_abort_steps first)";
+        if (s->ctx->tr[t].in_flight) return "a sweep is in flight (gmrm_sampler_end_sweep first)";
+    }
+    return nullptr;
+}
+
 // bayes.cpp:348-358: add the previous mu back, (it == 1) initial sigmae, draw the new mu
 int gmrm_sampler_draw_mu(gmrm_sampler* s, int it, double* mu_drawn) {
     if (!s || !mu_drawn) return fail(GMRM_EINVAL, "null argument");
@@ -144,10 +154,11 @@ int gmrm_sampler_draw_mu(gmrm_sampler* s, int it, double* mu_drawn) {
     return GMRM_OK;
 }
 
-// bayes.cpp:358-367 with the adopted mu, then the marker loop is launched (asynchronous)
-int gmrm_sampler_begin_sweep(gmrm_sampler* s, const double* mu_use) {
+// bayes.cpp:358-367 with the adopted mu, then the marker loop is launched (asynchronous); nothing else
+int gmrm_sampler_launch_sweep(gmrm_sampler* s, const double* mu_use) {
     if (!s || !mu_use) return fail(GMRM_EINVAL, "null argument");
     gmrm_ctx* ctx = s->ctx;
+    if (const char* why = busy_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_launch_sweep: ") + why);
     for (int t = 0; t < ctx->T; t++) {
         Chain& c = s->ch[t];
         c.mu = mu_use[t];
@@ -172,17 +183,31 @@ int gmrm_sampler_begin_sweep(gmrm_sampler* s, const double* mu_use) {
         in.rng_index = c.dist_d.idx;
         if (int r = gmrm_sweep_launch(ctx, t, &in)) return r;
     }
-    // The marker loops are running on the GPU (the order was copied at launch).  The next iteration's
-    // shuffle draws from dist_m only, a stream nothing else reads (phenotype.cpp:314-323): do it now, on
-    // the idle host, instead of in front of the next launch (~5 ms per million markers).  Not with
-    // --mimic-hydra, where the shuffle shares dist_d with the hyper-parameter draws of this iteration.
+    return GMRM_OK;
+}
+
+// The marker loops are running on the GPU (the order was copied at launch).  The next iteration's
+// shuffle draws from dist_m only, a stream nothing else reads (phenotype.cpp:314-323): do it now, on
+// the idle host, instead of in front of the next launch (~5 ms per million markers).  Not with
+// --mimic-hydra, where the shuffle shares dist_d with the hyper-parameter draws of this iteration.
+int gmrm_sampler_preshuffle(gmrm_sampler* s) {
+    if (!s) return fail(GMRM_EINVAL, "null sampler");
+    gmrm_ctx* ctx = s->ctx;
     if (s->shuffle && !s->mimic_hydra)
         for (int t = 0; t < ctx->T; t++) {
             Chain& c = s->ch[t];
+            if (c.preshuffled) continue;
             gm::shuffle(c.dist_m, c.midx.data(), ctx->M);
             c.preshuffled = true;
         }
     return GMRM_OK;
+}
+
+// bayes.cpp:358-367 with the adopted mu, the launch, and the next iteration's shuffle behind it (one shard per caller;
+// a host that drives several shards launches all of them first: gmrm_sampler_launch_sweep, then gmrm_sampler_preshuffle)
+int gmrm_sampler_begin_sweep(gmrm_sampler* s, const double* mu_use) {
+    if (int r = gmrm_sampler_launch_sweep(s, mu_use)) return r;
+    return gmrm_sampler_preshuffle(s);
 }
 
 // ---- the reference's per-step schedule (bayes.cpp:374-553 as several MPI tasks run it) -----------------------
@@ -193,13 +218,45 @@ int gmrm_sampler_begin_sweep(gmrm_sampler* s, const double* mu_use) {
 // chain is `mpiexec -n R gmrm`'s, not as a fast path (the sweep kernel is that).
 
 // bayes.cpp:358-367 with this shard's mu; no launch
+static int begin_steps_body(gmrm_sampler* s, const double* mu_use);
+
+// Leave a per-step sweep that cannot be completed (an error inside _begin_steps / _step, or in another shard of a
+// group): the residual gets this shard's mu back (what the next gmrm_sampler_draw_mu would add: c.mu is cleared), the
+// device keeps the effects / components of the last completed sweep, the host copies are dropped.  The RNG streams have
+// advanced: the chain can go on, it is no longer the chain it was.  Idempotent.
+int gmrm_sampler_abort_steps(gmrm_sampler* s) {
+    if (!s) return fail(GMRM_EINVAL, "null sampler");
+    gmrm_ctx* ctx = s->ctx;
+    int rc = GMRM_OK;
+    for (int t = 0; t < ctx->T; t++) {
+        Chain& c = s->ch[t];
+        if (!c.stepping) continue;
+        c.stepping = false;
+        if (int r = gmrm_offset_eps(ctx, t, c.mu)) rc = r;
+        c.mu = 0.0;
+    }
+    return rc;
+}
+
 int gmrm_sampler_begin_steps(gmrm_sampler* s, const double* mu_use) {
     if (!s || !mu_use) return fail(GMRM_EINVAL, "null argument");
     gmrm_ctx* ctx = s->ctx;
+    if (const char* why = busy_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_begin_steps: ") + why);
+    const int rc = begin_steps_body(s, mu_use);
+    if (rc != GMRM_OK) {                                          // phenotypes already switched over go back
+        const std::string keep = gmrm_last_error();
+        gmrm_sampler_abort_steps(s);
+        return fail(rc, keep);
+    }
+    return GMRM_OK;
+}
+
+static int begin_steps_body(gmrm_sampler* s, const double* mu_use) {
+    gmrm_ctx* ctx = s->ctx;
     for (int t = 0; t < ctx->T; t++) {
         Chain& c = s->ch[t];
-        if (c.stepping) return fail(GMRM_ESTATE, "gmrm_sampler_begin_steps: the previous per-step sweep was not ended");
         c.mu = mu_use[t];
+        c.stepping = true;                                        // from here on an abort has to add mu back
         if (int r = gmrm_offset_eps(ctx, t, -c.mu)) return r;
         if (s->shuffle && !c.preshuffled) gm::shuffle(s->mimic_hydra ? c.dist_d : c.dist_m, c.midx.data(), ctx->M);
         c.preshuffled = false;
@@ -213,7 +270,6 @@ int gmrm_sampler_begin_steps(gmrm_sampler* s, const double* mu_use) {
             if (int r = gmrm_get_marker_stats(ctx, t, c.mave.data(), c.msig.data())) return r;
         }
         c.n_updates = 0; c.n_batches = 0; c.n_planned = 0; c.n_stale = 0; c.n_fastb = 0; c.n_cross = 0; c.sweep_ms = 0.0;
-        c.stepping = true;
     }
     return GMRM_OK;
 }
@@ -427,6 +483,7 @@ int gmrm_sampler_get(gmrm_sampler* s, int t, gmrm_hyper* out) {
 int gmrm_sampler_save(gmrm_sampler* s, const char* path, int it) {
     if (!s || !path) return fail(GMRM_EINVAL, "null argument");
     gmrm_ctx* ctx = s->ctx;
+    if (const char* why = busy_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_save: ") + why);
     const std::string tmp = std::string(path) + ".tmp";
     FILE* f = std::fopen(tmp.c_str(), "wb");
     if (!f) return fail(GMRM_EIO, std::string("cannot write checkpoint ") + tmp);
@@ -460,6 +517,7 @@ int gmrm_sampler_save(gmrm_sampler* s, const char* path, int it) {
 int gmrm_sampler_load(gmrm_sampler* s, const char* path, int* it_out) {
     if (!s || !path || !it_out) return fail(GMRM_EINVAL, "null argument");
     gmrm_ctx* ctx = s->ctx;
+    if (const char* why = busy_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_load: ") + why);
     FILE* f = std::fopen(path, "rb");
     if (!f) return fail(GMRM_EIO, std::string("cannot open checkpoint ") + path);
     char magic[8];
@@ -483,6 +541,18 @@ int gmrm_sampler_load(gmrm_sampler* s, const char* path, int* it_out) {
              get(f, c.sigmag.data(), (size_t)s->G) && get(f, c.pi_est.data(), (size_t)s->G * s->K) &&
              get(f, betas.data(), (size_t)ctx->M) && get(f, comp.data(), (size_t)ctx->M) && get(f, eps.data(), eps.size());
         if (!ok) break;
+        {   // a damaged or foreign file must not reach the kernel: the visit order is a permutation of the block's markers
+            // (the kernel indexes the genotype block with it), components are below K, RNG positions within a block
+            std::vector<uint8_t> seen((size_t)std::max(1, ctx->M), 0);
+            bool good = c.dist_m.idx >= 0 && c.dist_m.idx <= 624 && c.dist_d.idx >= 0 && c.dist_d.idx <= 624 &&
+                        std::isfinite(sc[0]) && sc[0] > 0.0 && std::isfinite(sc[1]);
+            for (int i = 0; good && i < ctx->M; i++) {
+                const int m = c.midx[i];
+                if (m < 0 || m >= ctx->M || seen[(size_t)m]) good = false; else seen[(size_t)m] = 1;
+                if (comp[i] < 0 || comp[i] >= s->K || !std::isfinite(betas[i])) good = false;
+            }
+            if (!good) { rc = fail(GMRM_EINVAL, std::string("checkpoint ") + path + " holds an inconsistent chain state (visit order / components / RNG position)"); break; }
+        }
         c.sigmae = sc[0]; c.mu = sc[1]; c.epssum = sc[2]; c.preshuffled = flags[0] != 0;
         if ((rc = gmrm_upload_eps(ctx, t, eps.data())) != GMRM_OK) break;
         if (ctx->M > 0) {
@@ -491,6 +561,7 @@ int gmrm_sampler_load(gmrm_sampler* s, const char* path, int* it_out) {
             c.betas = betas;
         }
     }
+    if (ok && rc == GMRM_OK && std::fgetc(f) != EOF) { std::fclose(f); return fail(GMRM_EINVAL, std::string("checkpoint ") + path + " is longer than its header says"); }
     std::fclose(f);
     if (rc != GMRM_OK) return rc;
     if (!ok) return fail(GMRM_EIO, std::string("truncated checkpoint ") + path);

@@ -23,6 +23,7 @@
 
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using gm::fail;
@@ -171,14 +172,36 @@ extern "C" int gmrm_group_iterate(gmrm_group* g, int it) {
     std::vector<double> mu0(T), mu(T);
     for (int r = 0; r < n; r++)
         if (int rc = gmrm_sampler_draw_mu(g->smp[r], it, r == 0 ? mu0.data() : mu.data())) return rc;
+    // Every shard's marker loop is launched before anything else happens on the host (a shard's launch used to wait for
+    // the previous shard's next-iteration shuffle: ~0.6 ms per 125 000 markers, several ms of skew at eight shards); the
+    // shuffles and the end-of-sweep downloads (effects, counts, RNG state: blocking copies per device) then run on one
+    // host thread per shard.
     for (int r = 0; r < n; r++)
-        if (int rc = gmrm_sampler_begin_sweep(g->smp[r], mu0.data())) return rc;      // launches; returns at once
-    std::vector<int> cass((size_t)T * G * K, 0), c1((size_t)T * G * K);
-    std::vector<double> bsq((size_t)T * G, 0.0), b1((size_t)T * G);
+        if (int rc = gmrm_sampler_launch_sweep(g->smp[r], mu0.data())) return rc;     // launches; returns at once
+    std::vector<int> cass((size_t)T * G * K, 0);
+    std::vector<double> bsq((size_t)T * G, 0.0);
+    std::vector<std::vector<int>> c1(n, std::vector<int>((size_t)T * G * K));
+    std::vector<std::vector<double>> b1(n, std::vector<double>((size_t)T * G));
+    std::vector<int> rcs(n, GMRM_OK);
+    std::vector<std::string> errs(n);
+    auto finish = [&](int r) {
+        int rc = gmrm_sampler_preshuffle(g->smp[r]);
+        const int rc2 = gmrm_sampler_end_sweep(g->smp[r], c1[r].data(), b1[r].data());   // always: the sweep must be collected
+        if (rc == GMRM_OK) rc = rc2;
+        rcs[r] = rc;
+        if (rc != GMRM_OK) errs[r] = gmrm_last_error();                                 // the message is per thread
+    };
+    if (n == 1) finish(0);
+    else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < n; r++) th.emplace_back(finish, r);
+        for (auto& t : th) t.join();
+    }
+    for (int r = 0; r < n; r++)
+        if (rcs[r] != GMRM_OK) return fail(rcs[r], errs[r]);
     for (int r = 0; r < n; r++) {
-        if (int rc = gmrm_sampler_end_sweep(g->smp[r], c1.data(), b1.data())) return rc;
-        for (size_t i = 0; i < cass.size(); i++) cass[i] += c1[i];
-        for (size_t i = 0; i < bsq.size(); i++) bsq[i] += b1[i];                        // shard order, as a sequential MPI_SUM would
+        for (size_t i = 0; i < cass.size(); i++) cass[i] += c1[r][i];
+        for (size_t i = 0; i < bsq.size(); i++) bsq[i] += b1[r][i];                     // shard order, as a sequential MPI_SUM would
     }
     if (n > 1) {
         for (int t = 0; t < T; t++) {
@@ -209,8 +232,18 @@ extern "C" int gmrm_group_iterate(gmrm_group* g, int it) {
 // The chain is that of `mpiexec -n <shards> gmrm` (per-shard seeds, bayes.cpp:796-803).  Every step costs a
 // kernel launch and a device-to-host copy per shard plus one launch per changed marker and replica: the
 // reference's communication pattern, not a fast path -- gmrm_group_iterate is the schedule built for speed.
+static int group_iterate_steps_body(gmrm_group* g, int it);
 extern "C" int gmrm_group_iterate_steps(gmrm_group* g, int it) {
     if (!g) return fail(GMRM_EINVAL, "null group");
+    const int rc = group_iterate_steps_body(g, it);
+    if (rc != GMRM_OK) {                      // no shard stays inside a half-done per-step sweep (gmrm_sampler_abort_steps)
+        const std::string keep = gmrm_last_error();
+        for (int r = 0; r < g->n; r++) gmrm_sampler_abort_steps(g->smp[r]);
+        return fail(rc, keep);
+    }
+    return GMRM_OK;
+}
+static int group_iterate_steps_body(gmrm_group* g, int it) {
     const int n = g->n, T = g->T, G = g->G, K = g->K;
     std::vector<double> mu(T);
     int Mm = 0;

@@ -239,6 +239,11 @@ int gmrm_sampler_iterate(gmrm_sampler* s, int it);
 /* sharded: the same iteration cut at its exchange points (see DESIGN.md "Multi-GPU") */
 int gmrm_sampler_draw_mu(gmrm_sampler* s, int it, double* mu_drawn /*[T]*/);
 int gmrm_sampler_begin_sweep(gmrm_sampler* s, const double* mu_use /*[T]*/);  /* launches  */
+/* gmrm_sampler_begin_sweep = gmrm_sampler_launch_sweep (bayes.cpp:358-367 with the adopted mu and the launch, nothing
+ * else) + gmrm_sampler_preshuffle (the NEXT iteration's marker shuffle, on the idle host while the GPU sweeps).  A host
+ * that drives several shards launches all of them before it shuffles for any (gmrm_group_iterate does). */
+int gmrm_sampler_launch_sweep(gmrm_sampler* s, const double* mu_use /*[T]*/);
+int gmrm_sampler_preshuffle(gmrm_sampler* s);
 int gmrm_sampler_end_sweep(gmrm_sampler* s, int* cass /*[T*G*K]*/, double* beta_sqn /*[T*G]*/);
 int gmrm_sampler_epilogue(gmrm_sampler* s, const int* cass, const double* beta_sqn);
 int gmrm_sampler_adopt(gmrm_sampler* s, int t, const double* sigmag, const double* pi_est, double sigmae);
@@ -254,6 +259,10 @@ int gmrm_sampler_get(gmrm_sampler* s, int t, gmrm_hyper* out);
 int gmrm_sampler_begin_steps(gmrm_sampler* s, const double* mu_use /*[T]*/);
 int gmrm_sampler_step(gmrm_sampler* s, int mrki, int* mloc, double* dbeta3 /*[3T]*/);
 int gmrm_sampler_end_steps(gmrm_sampler* s, int* cass /*[T*G*K]*/, double* beta_sqn /*[T*G]*/);
+/* Leave a per-step sweep that cannot be completed (an error in _begin_steps / _step, here or in another shard): the
+ * residual gets mu back, the device keeps the effects of the last completed sweep.  gmrm_sampler_begin_sweep /
+ * _begin_steps / _save / _load return GMRM_ESTATE while a per-step sweep is open or a kernel sweep is in flight. */
+int gmrm_sampler_abort_steps(gmrm_sampler* s);
 /* one .csv record of phenotype t as write_ofile_csv formats it (src/xfiles.cpp:17-42) */
 int gmrm_sampler_csv_line(gmrm_sampler* s, int t, int it, char* buf, size_t len);
 /* Checkpoint / restart (no reference counterpart: Bayes::process deletes its outputs at start,

@@ -89,3 +89,67 @@ def test_residual_outside_the_exact_range_is_reported_from_inside_the_sweep(gpu)
     assert ei.value.code == GMRM_EKERNEL and "2^8" in str(ei.value)
     smp.close()
     ctx.close()
+
+
+def test_open_per_step_sweep_blocks_other_entries_and_can_be_aborted(gpu, tmp_path):
+    """while a per-step sweep is open (the device's effects are stale against the host copies, the residual is
+    offset by -mu) a kernel sweep, a second per-step sweep, a save and a load are refused; gmrm_sampler_abort_steps puts
+    the residual back and the sampler can go on."""
+    case = cases.CASE_BY_NAME["small"]
+    inp = cases.make_inputs(case)
+    ctx, _ = _setup(case, inp)
+    ctx.compute_markers_statistics(0)
+    smp = gmrm_amd.Sampler(ctx, case.seed, inp["cva"], inp["group_index"])
+    smp.iterate(1)
+    before = ctx.get_epsilon(0)
+    mu_prev = smp.hyper(0).mu
+    ck = tmp_path / "ck.bin"
+    smp.save(ck, 1)
+    mu = smp.draw_mu(2)                                            # residual += previous mu
+    smp.begin_steps(mu)                                            # residual -= mu
+    smp.step(0)
+    for call in (lambda: smp.begin_sweep(mu), lambda: smp.begin_steps(mu), lambda: smp.save(tmp_path / "x.bin", 1), lambda: smp.load(ck)):
+        with pytest.raises(GmrmError) as ei:
+            call()
+        assert ei.value.code == GMRM_ESTATE and "per-step sweep is open" in str(ei.value)
+    smp.abort_steps()
+    smp.abort_steps()                                              # idempotent
+    got = ctx.get_epsilon(0)                                       # draw_mu's offset stays; begin_steps' is undone
+    keep = np.repeat(~np.asarray(inp["isna"][0], dtype=bool), 1)
+    assert np.max(np.abs(got[:case.N][keep] - (before[:case.N][keep] + mu_prev))) < 1e-12
+    smp.load(ck)                                                   # and the chain state can be replaced again
+    smp.iterate(2)
+    want = cases.run_oracle(case, inp, iters=2, canon=True)
+    assert np.array_equal(ctx.betas(0), want[0]["betas"][1])
+    smp.close()
+    ctx.close()
+
+
+def test_checkpoint_with_a_damaged_visit_order_is_refused(gpu, tmp_path):
+    """the visit order of a checkpoint indexes the genotype block inside the kernel: a file whose header matches
+    but whose order is not a permutation (or whose components exceed K, or that is longer than its header says) is refused."""
+    case = cases.CASE_BY_NAME["small"]
+    inp = cases.make_inputs(case)
+    ctx, _ = _setup(case, inp)
+    ctx.compute_markers_statistics(0)
+    smp = gmrm_amd.Sampler(ctx, case.seed, inp["cva"], inp["group_index"])
+    smp.iterate(1)
+    ck = tmp_path / "ck.bin"
+    smp.save(ck, 1)
+    raw = bytearray(ck.read_bytes())
+    # layout: magic 8, header 12 ints, then per phenotype: 3 doubles, 1 int, 624 + 1 ints, 624 + 1 ints, midx[M] ints, ...
+    off_midx = 8 + 48 + 24 + 4 + 625 * 4 * 2
+    bad = bytearray(raw)
+    bad[off_midx:off_midx + 4] = (10 ** 6).to_bytes(4, "little")           # an index far outside the block
+    (tmp_path / "bad1.bin").write_bytes(bad)
+    bad = bytearray(raw)
+    bad[off_midx:off_midx + 4] = bad[off_midx + 4:off_midx + 8]            # a duplicate: not a permutation
+    (tmp_path / "bad2.bin").write_bytes(bad)
+    (tmp_path / "bad3.bin").write_bytes(bytes(raw) + b"\0" * 8)            # trailing bytes
+    for name in ("bad1.bin", "bad2.bin", "bad3.bin"):
+        with pytest.raises(GmrmError) as ei:
+            smp.load(tmp_path / name)
+        assert "checkpoint" in str(ei.value)
+    assert smp.load(ck) == 1                                               # the intact file still loads
+    smp.close()
+    ctx.close()

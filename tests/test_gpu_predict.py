@@ -71,9 +71,15 @@ def test_assoc_over_many_blocks_and_scales(gpu, scale):
         assert np.array_equal(g, orc.predict_g(inp["bed"], mask4, mave, msig, beta)[:case.N])
         zero = ctx.assoc(0, np.zeros(case.N))[1]
         assert not zero.any()
+        present = np.flatnonzero(inp["isna"][0] == 0)
+        absent = np.flatnonzero(inp["isna"][0] != 0)
         bad = yk.copy()
-        bad[5] = np.inf
+        bad[present[5]] = np.inf
         assert np.isnan(ctx.assoc(0, bad)[1]).all()              # a non-finite phenotype is reported, not summed
+        ok = yk.copy()
+        ok[absent[:3]] = [np.nan, np.inf, 1e300]                 # ... but not where the individual has no phenotype:
+        xtx2, xty2 = ctx.assoc(0, ok)                            # those never enter the sums and must not set the scale
+        assert np.array_equal(xtx2, xtx) and np.array_equal(xty2, xty)
     finally:
         ctx.close()
 
