@@ -182,6 +182,7 @@ def main():
     CPU_THREADS = min(len(os.sched_getaffinity(0)), int(os.environ.get("GMRM_CPU_THREADS", "16")))
     os.environ["OMP_NUM_THREADS"] = str(CPU_THREADS)
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before HIP initialises: four phenotype chains on four hardware queues
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -158,6 +158,9 @@ def load_library():
     if _LIB is not None:
         return _LIB
     path = library_path()
+    # eight hardware queues, so that four persistent sweeps on four streams run side by side (capi.cpp, want_hw_queues);
+    # set here as well because torch may initialise the HIP runtime before libgmrm_hip.so is loaded
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     _share_torch_hip_runtime()
     if not path.exists():
         raise ImportError(f"{path} is missing: build it with `python -m gmrm_amd.build` "

@@ -22,6 +22,12 @@
 
 namespace gm {
 
+// Phenotypes sweep side by side as persistent launches on streams of their own, and a persistent kernel holds its
+// hardware queue until it ends.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of
+// them shared with the null stream): with four chains the fourth queued behind the third (kernel trace: three sweeps
+// together, then one).  Ask for eight before the runtime initialises, unless the user has set it.
+__attribute__((constructor)) static void want_hw_queues() { ::setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 static thread_local std::string g_err;
 int fail(int code, const std::string& msg) { g_err = msg; return code; }
 static int hip_fail(hipError_t e, const char* what) {
