@@ -16,6 +16,8 @@ def read_pass(path):
         name = r["Kernel_Name"].replace("void ", "").split("(")[0]
         if not name.startswith("gm::"):
             continue
+        if name.startswith("gm::k_sweep<"):              # one family: the early dense sweeps run the continuation instantiation
+            name = "gm::k_sweep"
         k = (name, int(r["Dispatch_Id"]))
         per.setdefault(k, {}).setdefault(r["Counter_Name"], 0.0)
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])

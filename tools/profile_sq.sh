@@ -17,7 +17,7 @@ for wl in $WLS; do
   for p in A B C; do
     eval "CNT=\$PASS_$p"
     echo "== $wl pass $p: $CNT"
-    timeout -k 10 400 rocprofv3 --pmc $CNT --output-format csv -d $OUT/sq_${wl}_$p -- python3 $ROOT/bench.py --workload $wl --steps 2 --warmup 3 --no-cpu-baseline --no-signal \
+    timeout -k 10 400 rocprofv3 --pmc $CNT --output-format csv -d $OUT/sq_${wl}_$p -- python3 $ROOT/bench.py --workload $wl --steps 2 --warmup 5 --no-cpu-baseline --no-signal \
       > $OUT/bench_under_sq_${wl}_$p.json 2> $OUT/rocprof_sq_${wl}_$p.err || { tail -5 $OUT/rocprof_sq_${wl}_$p.err; exit 1; }
   done
   python3 $ROOT/tools/pmc_sq_summary.py $OUT/${TAG}_pmc_sq_${wl}.json 2 $wl \
