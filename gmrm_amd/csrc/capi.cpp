@@ -656,15 +656,16 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.spec_factor16 = c->spec_factor16;
     a.miss_mode = tr.miss_mode;
     if (std::getenv("GMRM_FORCE_MIXED")) a.miss_mode = 1;     // diagnostic: run any block through the per-marker-layout kernel
-    // The walk may cross markers whose effect was non-zero when no marker of the block has a missing genotype among the
-    // phenotyped individuals (then mave * nonas is the integer sum of a marker's genotype values; flags and means come
-    // from gmrm_marker_stats: values set through gmrm_set_marker_stats leave miss_mode at 2).  The kernel with that code
+    // The walk may cross markers whose effect was non-zero: when no marker of the block has a missing genotype among the
+    // phenotyped individuals (mode 0: mave * nonas is then the integer sum of a marker's genotype values; flags and means
+    // come from gmrm_marker_stats -- values set through gmrm_set_marker_stats leave miss_mode at 2), or when every marker
+    // is treated as having some (mode 2: everything the patch needs is counted inside the kernel).  The kernel with that code
     // is ~3 % slower in rounds that cross nothing, and a crossing costs about half a round, so it is launched only when
     // enough markers are in the model (their number is known: the previous sweep's component counts) -- measured on
     // 500k x 1M: 7.8 % in the model 690 -> 470 ms per sweep, 1.7 % 202 -> 181, 0.36 % (stationary) 132 -> 136.  The chain
     // is the same either way, bit for bit.  GMRM_NO_CROSS=1 / GMRM_FORCE_CROSS=1: A/B knobs.
     a.cross = 0;
-    if (a.miss_mode == 0 && !std::getenv("GMRM_NO_CROSS")) {
+    if ((a.miss_mode == 0 || a.miss_mode == 2) && !std::getenv("GMRM_NO_CROSS")) {      // (the mixed layout, mode 1, has no such kernel)
         const bool dense = (double)tr.in_model >= c->cross_density * (double)c->M;
         if (dense || std::getenv("GMRM_FORCE_CROSS")) a.cross = c->cross_frac16;
     }

@@ -531,40 +531,62 @@ struct Walk {
 // the sums of the markers behind it (exact integers, see above) and walks on, crossing further registered stops itself.
 // Two instantiations of the same code: the first stays the straight-line two-pass code the compiler makes of it when
 // nothing can resume inside (its loop-carried state is small), the second is a general loop entered ~0.3 times per round.
-template <int K, bool CONT, bool HOT, class TP>
+template <int K, int CK, bool HOT, class TP>
 __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, TP tab,
                                            const LaneIn& lin0, const LaneIn& lin1, Totals& tq0, Totals& tq1,
                                            const Draws draws, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass,
                                            int ns, int ps0, int ps1) {
+    constexpr bool CONT = CK != 0;
     const int lane = threadIdx.x & 63;
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     const UpdList ul = upd_list(smem);
     int* s_cass = reinterpret_cast<int*>(smem + l_cass);
     LdsStream rs{reinterpret_cast<const uint32_t*>(smem + L_RNG0), reinterpret_cast<const uint32_t*>(smem + L_RNG1),
                  w.cursor, &ctl[C_RNGERR]};
+    // The sums of the markers behind the crossed marker w.at, patched in place (exact integers, see above).  CK == 1: no
+    // marker of the block has a missing genotype among the phenotyped individuals -- one packed G per marker behind the stop
+    // (stop w.q in bits 24 q ..), X_j = mave_j * nonas, a common b-sum.  CK == 2: every marker may have missing genotypes --
+    // per marker behind the stop two slots {Ga | Gab << 26, Za | Zb << 26} (sum a_j a_s, sum a_j b_s, sum miss_j a_s,
+    // sum miss_j b_s over the phenotyped individuals) and per stop {A_s, B_s} = {sum a_s, sum b_s}:
+    //     sum a_j eps += alpha_ Ga + beta_ Gab        sum b_j eps += alpha_ (A_s - Za) + beta_ (B_s - Zb)
+    auto patch = [&]() {
+        const double* s_tot = reinterpret_cast<const double*>(smem + L_TOT);
+        if constexpr (CK == 1) {
+            const double nonas = nm1 + 1.0;
+            const __int128 cb = (__int128)w.ai * w.xs + (__int128)w.bi * (long long)nonas;
+            const long long x0 = (long long)__builtin_rint(lin0.mave * nonas), x1 = (long long)__builtin_rint(lin1.mave * nonas);
+            long long ex0 = 0, ex1 = 0;
+            if (lane > ps0 && lane < nb) ex0 = (long long)s_tot[2 * nb + 2 + lane - ps0 - 1];
+            if (lane + 64 > ps0 && lane + 64 < nb) ex1 = (long long)s_tot[2 * nb + 2 + lane + 64 - ps0 - 1];
+            const long long g0 = w.q ? (ex0 >> 24) : (ex0 & 0xFFFFFFll), g1 = w.q ? (ex1 >> 24) : (ex1 & 0xFFFFFFll);
+            if (lane > w.at) {
+                exact_split(exact_sum(tq0.t0, tq0.t1) + ((__int128)w.ai * g0 + (__int128)w.bi * x0), tq0.t0, tq0.t1);
+                exact_split(exact_sum(tq0.t2, tq0.t3) + cb, tq0.t2, tq0.t3);
+            }
+            if (lane + 64 > w.at) {
+                exact_split(exact_sum(tq1.t0, tq1.t1) + ((__int128)w.ai * g1 + (__int128)w.bi * x1), tq1.t0, tq1.t1);
+                exact_split(exact_sum(tq1.t2, tq1.t3) + cb, tq1.t2, tq1.t3);
+            }
+        } else {
+            const int nv0 = 4 * nb + 2;
+            const long long As = (long long)s_tot[nv0], Bs = (long long)s_tot[nv0 + 1];
+            auto one = [&](int p, Totals& t) {
+                if (p > w.at && p < nb) {
+                    const long long e0 = (long long)s_tot[nv0 + 2 + 2 * (p - ps0 - 1)], e1 = (long long)s_tot[nv0 + 3 + 2 * (p - ps0 - 1)];
+                    const long long ga = e0 & 0x3FFFFFFll, gab = e0 >> 26, za = e1 & 0x3FFFFFFll, zb = e1 >> 26;
+                    exact_split(exact_sum(t.t0, t.t1) + ((__int128)w.ai * ga + (__int128)w.bi * gab), t.t0, t.t1);
+                    exact_split(exact_sum(t.t2, t.t3) + ((__int128)w.ai * (As - za) + (__int128)w.bi * (Bs - zb)), t.t2, t.t3);
+                }
+            };
+            one(lane, tq0);
+            one(lane + 64, tq1);
+        }
+    };
     int cursor = w.cursor, run = w.run, nupd = w.nupd, ncross = w.ncross, from = w.from, ndone = w.ndone;
     bool stopped = false, planned = false, repeek = w.repeek;
     int part = from >> 6;
-    if (!HOT) {
-        // the walk goes on behind the marker the first piece stopped at: patch the sums of the markers behind it
-        const double nonas = nm1 + 1.0;
-        const __int128 cb = (__int128)w.ai * w.xs + (__int128)w.bi * (long long)nonas;
-        const long long x0 = (long long)__builtin_rint(lin0.mave * nonas), x1 = (long long)__builtin_rint(lin1.mave * nonas);
-        // the exchanged G values of this lane's two positions (packed: stop 0 in bits 0..23, stop 1 in bits 24..47), still
-        // in LDS where poll_totals left the batch's totals
-        const double* s_tot = reinterpret_cast<const double*>(smem + L_TOT);
-        long long ex0 = 0, ex1 = 0;
-        if (lane > ps0 && lane < nb) ex0 = (long long)s_tot[2 * nb + 2 + lane - ps0 - 1];
-        if (lane + 64 > ps0 && lane + 64 < nb) ex1 = (long long)s_tot[2 * nb + 2 + lane + 64 - ps0 - 1];
-        const long long g0 = w.q ? (ex0 >> 24) : (ex0 & 0xFFFFFFll), g1 = w.q ? (ex1 >> 24) : (ex1 & 0xFFFFFFll);
-        if (lane > w.at) {
-            exact_split(exact_sum(tq0.t0, tq0.t1) + ((__int128)w.ai * g0 + (__int128)w.bi * x0), tq0.t0, tq0.t1);
-            exact_split(exact_sum(tq0.t2, tq0.t3) + cb, tq0.t2, tq0.t3);
-        }
-        if (lane + 64 > w.at) {
-            exact_split(exact_sum(tq1.t0, tq1.t1) + ((__int128)w.ai * g1 + (__int128)w.bi * x1), tq1.t0, tq1.t1);
-            exact_split(exact_sum(tq1.t2, tq1.t3) + cb, tq1.t2, tq1.t3);
-        }
+    if (!HOT) {                                      // the walk goes on behind the marker the first piece stopped at
+        patch();
         ncross++;
     }
     w.q = -1;
@@ -683,23 +705,7 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, T
                 w.ai = (long long)(al * GRID_INV); w.bi = (long long)(be * GRID_INV);
                 w.xs = (long long)__builtin_rint(readlane64(in.mave, s) * (nm1 + 1.0));
                 if (HOT) break;                                          // the continuation takes over
-                // (second piece) patch and walk on
-                const double nonas = nm1 + 1.0;
-                const __int128 cb = (__int128)w.ai * w.xs + (__int128)w.bi * (long long)nonas;
-                const long long x0 = (long long)__builtin_rint(lin0.mave * nonas), x1 = (long long)__builtin_rint(lin1.mave * nonas);
-                const double* s_tot = reinterpret_cast<const double*>(smem + L_TOT);
-                long long ex0 = 0, ex1 = 0;
-                if (lane > ps0 && lane < nb) ex0 = (long long)s_tot[2 * nb + 2 + lane - ps0 - 1];
-                if (lane + 64 > ps0 && lane + 64 < nb) ex1 = (long long)s_tot[2 * nb + 2 + lane + 64 - ps0 - 1];
-                const long long g0 = q ? (ex0 >> 24) : (ex0 & 0xFFFFFFll), g1 = q ? (ex1 >> 24) : (ex1 & 0xFFFFFFll);
-                if (lane > w.at) {
-                    exact_split(exact_sum(tq0.t0, tq0.t1) + ((__int128)w.ai * g0 + (__int128)w.bi * x0), tq0.t0, tq0.t1);
-                    exact_split(exact_sum(tq0.t2, tq0.t3) + cb, tq0.t2, tq0.t3);
-                }
-                if (lane + 64 > w.at) {
-                    exact_split(exact_sum(tq1.t0, tq1.t1) + ((__int128)w.ai * g1 + (__int128)w.bi * x1), tq1.t0, tq1.t1);
-                    exact_split(exact_sum(tq1.t2, tq1.t3) + cb, tq1.t2, tq1.t3);
-                }
+                patch();                                                 // (second piece) patch and walk on
                 ncross++;
                 w.q = -1;
                 if (from >= base + nbp) part++;
@@ -717,7 +723,7 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, T
     w.stopped = stopped; w.planned = planned; w.repeek = repeek;
 }
 
-template <int K, bool CONT, class TP>
+template <int K, int CK, class TP>
 __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
                                                   const LaneIn& lin0, const LaneIn& lin1, Totals& tq0, Totals& tq1,
                                                   const Draws draws, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass,
@@ -730,10 +736,10 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
     Walk w;
     w.cursor = ctl[C_CURSOR]; w.run = 2 * nb; w.nupd = 0; w.ncross = 0; w.from = 0; w.ndone = nb;
     w.stopped = false; w.planned = false; w.repeek = false; w.q = -1; w.at = 0; w.ai = 0; w.bi = 0; w.xs = 0;
-    walk_piece<K, CONT, true>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
-    if (CONT) {
+    walk_piece<K, CK, true>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
+    if (CK != 0) {
         if (__builtin_expect(w.q >= 0, 0))                           // (uniform) the walk met a marker it may cross
-            walk_piece<K, true, false>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
+            walk_piece<K, CK, false>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
     }
     if (lane == 0) {
         ctl[C_UPD] = w.nupd;
@@ -753,13 +759,13 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
 }
 
 // K = 4 (the reference's example mixtures) is inlined into the kernel; other K share out-of-line copies.
-template <int K, bool CONT, class TP>
+template <int K, int CK, class TP>
 __device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
                                           const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
                                           double p0, double p1, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass,
                                           int ns, int ps0, int ps1) {
     Totals tq0 = tot0, tq1 = tot1;
-    sample_batch_body<K, CONT>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tq0, tq1, Draws{p0, p1}, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
+    sample_batch_body<K, CK>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tq0, tq1, Draws{p0, p1}, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
 }
 
 // rank of batch position p among the dirty markers of the batch (dm0: positions 0..63, dm1: 64..127)
@@ -966,7 +972,8 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
 // sweeps in which enough markers are in the model for the crossings to pay (capi.cpp, gmrm_sweep_launch).
 template <int R, int MODE, bool CONT>
 __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
-    static_assert(!CONT || MODE == 0, "continuation: fast layout only");
+    static_assert(!CONT || MODE == 0 || MODE == 2, "continuation: the fast layout and the all-dirty layout");
+    constexpr int CK = !CONT ? 0 : (MODE == 0 ? 1 : 2);   // 1: no marker has a missing genotype (among the phenotyped), 2: every marker may
     constexpr bool FAST = MODE == 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GE = Geo<R>;
@@ -1338,11 +1345,16 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 };
                 b.ns = 1; b.ps0 = pop_first();
                 int last = pop_first();                          // the stop that ends the batch, if any
-                if (NSTOP > 1 && last >= 0 && last + 1 < b.nb && last + cross_thr <= b.nb - 1) {
+                if (CK == 2) {                                   // 4 slots per marker + 2 for the stop + 2 per marker behind it
+                    const int fit = (SW_VMAX - 2 + 2 * b.ps0) / 6;
+                    if (b.nb > fit) b.nb = fit;
+                }
+                if (CK == 1 && NSTOP > 1 && last >= 0 && last + 1 < b.nb && last + cross_thr <= b.nb - 1) {
                     b.ns = 2; b.ps1 = last; last = pop_first();
                 }
                 if (last >= 0 && last + 1 < b.nb) b.nb = last + 1;
-                b.planned = last >= 0;
+                b.planned = last >= 0 && last < b.nb;
+                if (b.ps0 + 1 >= b.nb) { b.ns = 0; b.planned = true; }   // (the slots left nobody behind it: the batch ends at the marker)
             } else {
                 if (first + 1 < b.nb) b.nb = first + 1;
                 b.planned = first < b.nb;                        // the last marker of the batch has a non-zero effect
@@ -1434,17 +1446,36 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             for (int q = 0; q < ns; q++) {
                 const int ps = p0 + (q ? ps1 : ps0);
                 const char* own = ring + (size_t)rmod(ps) * SB + 16 * (o_chunk ^ (ps & (CPP - 1))) + o_jb;
-                uint32_t pv[ND];
+                uint32_t pv[ND], pb[ND];
+                int suma = 0, sumb = 0;
 #pragma unroll
                 for (int d = 0; d < ND; d++) {
                     const uint32_t x = ((*reinterpret_cast<const uint32_t*>(own + 4 * d) | na_or[d]) >> (2 * o_fld)) & 0x03030303u;
                     const uint32_t miss = x & (x >> 1) & 0x01010101u;            // ring code 3: missing genotype (or no phenotype)
                     pv[d] = x & ~(miss | (miss << 1));
+                    pb[d] = miss ^ 0x01010101u;                                  // b_s: 1 unless missing
+                    suma += (int)((pv[d] * 0x01010101u) >> 24);                  // byte sums (<= 8, <= 4)
+                    sumb += (int)((pb[d] * 0x01010101u) >> 24);
                 }
                 char* dst = planes + (7 + q) * PST + 64 + p0w;
                 if constexpr (ND == 1) *reinterpret_cast<uint32_t*>(dst) = pv[0];
                 else if constexpr (ND == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pv[0], pv[1]);
                 else *reinterpret_cast<uint4*>(dst) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
+                if constexpr (CK == 2) {
+                    // the all-dirty layout has one stop: its second plane holds b_s, and the slice's sums of both planes
+                    // (A_s = sum a_s, B_s = sum b_s over the phenotyped individuals) are exchanged like everything else
+                    char* dstb = planes + 8 * PST + 64 + p0w;
+                    if constexpr (ND == 1) *reinterpret_cast<uint32_t*>(dstb) = pb[0];
+                    else if constexpr (ND == 2) *reinterpret_cast<uint2*>(dstb) = make_uint2(pb[0], pb[1]);
+                    else *reinterpret_cast<uint4*>(dstb) = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+                    int pk = suma | (sumb << 16);                                // both sums of a wavefront fit 16 bits (<= 64 * 32)
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) pk += __shfl_xor(pk, o, 64);
+                    if (lane == 0) {
+                        atomicAdd(&s_sum[4 * b.nb + 2], (unsigned long long)(pk & 0xFFFF));
+                        atomicAdd(&s_sum[4 * b.nb + 3], (unsigned long long)(pk >> 16));
+                    }
+                }
             }
             lds_barrier();
         }
@@ -1560,8 +1591,21 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     for (int r = 0; r < 4; r++) {
                         const int m = 16 * (t + q * tsplit) + 4 * kg + r;
                         const int xr = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);
-                        if (n == 8 && m > ps0 && m < nb) atomicAdd(&s_sum[2 * nb + 2 + m - ps0 - 1], (unsigned long long)xr);
-                        if (n == 9 && ns > 1 && m > ps1 && m < nb) atomicAdd(&s_sum[2 * nb + 2 + m - ps0 - 1], (unsigned long long)xr << 24);
+                        if constexpr (CK == 1) {
+                            if (n == 8 && m > ps0 && m < nb) atomicAdd(&s_sum[2 * nb + 2 + m - ps0 - 1], (unsigned long long)xr);
+                            if (n == 9 && ns > 1 && m > ps1 && m < nb) atomicAdd(&s_sum[2 * nb + 2 + m - ps0 - 1], (unsigned long long)xr << 24);
+                        } else if constexpr (!TF) {
+                            // all-dirty layout: column 8 = a_s, column 9 = b_s of the one stop; per marker behind it
+                            //   slot 0: G_a | G_ab << 26 = sum a_j a_s | sum a_j b_s  (a_j = c' - 3 [missing]: X - 3 Z)
+                            //   slot 1: Z_a | Z_b << 26  = sum [j missing] a_s | sum [j missing] b_s
+                            const int zr = zcc0[q][r] + (zcc1[q][r] >> 2) + (zcc2[q][r] >> 4);
+                            if ((n == 8 || n == 9) && m > ps0 && m < nb) {
+                                const int sl = 4 * nb + 4 + 2 * (m - ps0 - 1);
+                                const int sh = n == 9 ? 26 : 0;
+                                atomicAdd(&s_sum[sl], (unsigned long long)(long long)(xr - 3 * zr) << sh);
+                                atomicAdd(&s_sum[sl + 1], (unsigned long long)(long long)zr << sh);
+                            }
+                        }
                     }
                 }
             }
@@ -1592,7 +1636,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         lds_barrier();                                // the LDS sums are complete (prefetches stay in flight)
         PA(3);
         const int nv0 = 2 * nb + 2 + 2 * nd;
-        const int nv = nv0 + ((CONT && ns > 0) ? nb - 1 - ps0 : 0);   // behind a crossed stop: one more value per marker
+        // behind a crossed stop: one more value per marker (two, and two for the stop, in the all-dirty layout)
+        const int nv = nv0 + ((CONT && ns > 0) ? (CK == 2 ? 2 + 2 * (nb - 1 - ps0) : nb - 1 - ps0) : 0);
         if (CONT && ns > 0) {                       // (uniform) packed G counts: integers < 2^48, exact as doubles
             for (int vi = nv0 + tid; vi < nv; vi += SW_TPB) {
                 const double tot = (double)(long long)s_sum[vi];
@@ -1779,19 +1824,19 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 // the tables are read through a pointer of known address space (LDS)
                 auto run_step = [&](auto tabq) {
                     if (K == 4) {
-                        sample_batch_body<4, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, draws, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1);
+                        sample_batch_body<4, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, draws, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1);
                     } else {
                         // out-of-line copies take their inputs by address: hand them copies, so that the
                         // loop-carried lane inputs themselves stay in registers (no scratch round trips)
                         const LaneIn lc0 = li_cur0, lc1 = li_cur1;
                         const Totals tc0 = tot0, tc1 = tot1;
                         switch (K) {
-                            case 2: sample_batch<2, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 3: sample_batch<3, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 5: sample_batch<5, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 6: sample_batch<6, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 7: sample_batch<7, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            default: sample_batch<8, CONT>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 2: sample_batch<2, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 3: sample_batch<3, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 5: sample_batch<5, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 6: sample_batch<6, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 7: sample_batch<7, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            default: sample_batch<8, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
                         }
                     }
                 };
@@ -1914,7 +1959,7 @@ template <int R, int MODE, bool CONT> static hipError_t launch_RF(const SweepArg
 template <int R> static hipError_t launch_R(const SweepArgs& a, hipStream_t st, int grid) {
     switch (a.miss_mode) {
         case 0: return a.cross > 0 ? launch_RF<R, 0, true>(a, st, grid) : launch_RF<R, 0, false>(a, st, grid);
-        case 2: return launch_RF<R, 2, false>(a, st, grid);
+        case 2: return a.cross > 0 ? launch_RF<R, 2, true>(a, st, grid) : launch_RF<R, 2, false>(a, st, grid);
         default: return launch_RF<R, 1, false>(a, st, grid);
     }
 }
