@@ -288,12 +288,18 @@ def main():
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (it cannot
         # be read inside this process); the committed summary of the same workload is quoted.
         traffic = None
-        pmc = ROOT / "profiles" / "r02_pmc_summary.json"
-        if pmc.exists() and a.workload == "c3" and world == 1 and not a.markers and not a.individuals:
+        mfma_busy = None
+        pmc = ROOT / "profiles" / "r03_pmc_summary.json"
+        sq = ROOT / "profiles" / "r03_pmc_sq_summary.json"
+        if a.workload == "c3" and world == 1 and not a.markers and not a.individuals:
             try:
                 traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_k_sweep"]
             except Exception:
                 traffic = None
+            try:
+                mfma_busy = json.loads(sq.read_text())["c3"]["ratios"]["mfma_busy_cycles_over_busy_cu_cycles"]
+            except Exception:
+                mfma_busy = None
         mbytes = ctx.mbytes
         value = Mt * T * a.steps / dt
         avg_kernel_s = (sum(kern_ms) / len(kern_ms)) / 1e3
@@ -312,7 +318,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "bytes per launch: 2 x FETCH_SIZE (the gfx950 correction for 16-B/lane loads) + WRITE_SIZE from "
-                                         "profiles/r02_pmc_summary.json (separate rocprofv3 --pmc passes of this workload)" if traffic else None,
+                                         "profiles/r03_pmc_summary.json (separate rocprofv3 --pmc passes of this workload, stationary sweeps)" if traffic else None,
+                         "mfma_busy_frac": mfma_busy,
+                         "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES of the sweep kernel from profiles/r03_pmc_sq_summary.json "
+                                           "(rocprofv3 --pmc pass of this workload): the matrix cores take the dots, but the kernel waits ~half of "
+                                           "its wave-cycles (SQ_WAIT_ANY) on the grid-wide exchange" if mfma_busy is not None else None,
                          "kernel": "gm::k_sweep (persistent marker loop)",
                          "kernel_ms_avg": avg_kernel_s * 1e3,
                          "kernel_ms_per_launch": kern_ms, "kernel_ms_warmup_launches": warm_ms,
