@@ -516,6 +516,7 @@ int gmrm_predict_g(gmrm_ctx* c, int t, const double* beta_local, double* g) {
     if (!tr.have_stats) return fail(GMRM_ESTATE, "marker statistics not computed (gmrm_marker_stats)");
     HIPCHK(hipSetDevice(c->device));
     double *d_beta = nullptr, *d_g = nullptr;
+    void* d_ws = nullptr;
     int rc = GMRM_OK;
     hipError_t e;
     if ((e = dalloc(&d_beta, (size_t)std::max(1, c->M))) != hipSuccess) return hip_fail(e, "hipMalloc");
@@ -524,12 +525,19 @@ int gmrm_predict_g(gmrm_ctx* c, int t, const double* beta_local, double* g) {
         if ((e = hipMemset(d_g, 0, 4 * c->stride * sizeof(double))) != hipSuccess) break;
         if ((e = hipMemcpy(d_beta, beta_local, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
         if ((e = hipDeviceSynchronize()) != hipSuccess) break;
-        if ((e = launch_predict_g(c->bed, tr.namask2, c->stride, c->M, tr.mave, tr.msig, d_beta, d_g, tr.stream)) != hipSuccess) break;
+        // No marker of the block with a missing genotype among the phenotyped individuals (the marker statistics' flags): the
+        // contraction over markers runs on the matrix cores, exact sum rounded once (ops.hip, k_pg_mfma); otherwise the
+        // in-order f64 kernel.  GMRM_PREDICT_LUT=1 forces the latter.
+        if (tr.miss_mode == 0 && !std::getenv("GMRM_PREDICT_LUT")) {
+            if ((e = hipMalloc(&d_ws, predict_workspace_bytes(c->stride, c->M))) != hipSuccess) break;
+            if ((e = launch_predict_g_mfma(c->bed, tr.namask2, c->stride, c->M, tr.mave, tr.msig, d_beta, d_g, d_ws, tr.stream)) != hipSuccess) break;
+        } else if ((e = launch_predict_g(c->bed, tr.namask2, c->stride, c->M, tr.mave, tr.msig, d_beta, d_g, tr.stream)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(tr.stream)) != hipSuccess) break;
         e = hipMemcpy(g, d_g, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost);
     } while (0);
     if (e != hipSuccess) rc = hip_fail(e, "gmrm_predict_g");
     (void)hipFree(d_beta); (void)hipFree(d_g);
+    if (d_ws) (void)hipFree(d_ws);
     return rc;
 }
 

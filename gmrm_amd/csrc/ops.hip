@@ -608,6 +608,255 @@ hipError_t launch_selftest(int op, const double* x, double* y, int n, hipStream_
     return hipGetLastError();
 }
 
+// ---- k_predict_g on the matrix cores ----------------------------------------------------------
+// g_i = na_i * sum_m b_im (a_im C_m - D_m),  C_m = msig_m beta_m,  D_m = mave_m C_m   (bayes.cpp:93-122; upstream adds the terms
+// with `omp atomic`, i.e. in no order: the EXACT sum of these terms rounded once is inside the contract, tests: 1e-12).
+// Contraction over MARKERS: out[plane][individual] = sum_m digit_plane(C_m) * a_im with v_mfma_i32_16x16x64_i8 -- operand A =
+// the eight signed base-256 digit planes of the two exact parts of C_m 2^sh (split2; rows 0..7), operand B = the genotype
+// values of 16 individuals x 64 markers.  The .bed block is marker-major (a dword = 16 individuals of ONE marker), so the
+// 2-bit codes are transposed on the way: the 16 lanes of a DPP row each load one marker's dword and a 16 x 16 transpose of
+// 2-bit fields (four butterfly stages: DPP moves + v_alignbit + v_bfi) leaves lane n with individual n's codes of the 16
+// markers.  Four such dwords are the lane's 16 bytes of operand B; as in the sweep kernel, MFMA i takes field i of every
+// byte (one v_and per register) and the factor 4^i is divided out of that field's accumulator.  For a block whose markers
+// have no missing genotype among the phenotyped individuals b = 1 wherever the output is kept, so
+// g_i = sum_m a_im C_m - sum_m D_m with the second sum one exact constant (k_pg_planes).  Blocks with missing genotypes
+// go through k_predict_g<BW> above (same values to 1e-12, in-order f64 sum).
+constexpr int PG_KB = 2048;                         // markers per LDS stage (8 super-steps of 256)
+constexpr int PG_STAGES = 16;                       // stages per workgroup: 32 768 markers
+typedef int pg_v4i __attribute__((ext_vector_type(4)));
+
+__global__ void k_pg_absmax(const double* __restrict__ mave, const double* __restrict__ msig, const double* __restrict__ beta,
+                            int M, unsigned long long* __restrict__ out) {
+    unsigned long long mx = 0ull;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        const double c = msig[m] * beta[m];
+        const double d = mave[m] * c;
+        const unsigned long long bc = (unsigned long long)__double_as_longlong(fabs(c)), bd = (unsigned long long)__double_as_longlong(fabs(d));
+        mx = bc > mx ? bc : mx;
+        mx = bd > mx ? bd : mx;                    // |x| as bits: monotone for finite values; NaN / Inf end up on top
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned long long v = ((unsigned long long)(unsigned)__shfl_xor((int)(mx >> 32), o, 64) << 32) | (unsigned)__shfl_xor((int)mx, o, 64);
+        mx = v > mx ? v : mx;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, mx);
+}
+// plane byte of marker mu (within the padded block) for operand A: super-step ss = mu >> 8, then [kg][field i][dword j][byte b]
+// with mu & 255 = 64 kg + 16 j + 4 b + i
+__device__ __forceinline__ size_t pg_plane_index(size_t mu) {
+    const size_t r = mu & 255;
+    return (mu & ~(size_t)255) + (r & 192) + ((r & 3) << 4) + (((r >> 4) & 3) << 2) + ((r >> 2) & 3);
+}
+__global__ void k_pg_planes(const double* __restrict__ mave, const double* __restrict__ msig, const double* __restrict__ beta,
+                            int M, size_t Mpad, const unsigned long long* __restrict__ maxbits, uint8_t* __restrict__ planes,
+                            long long* __restrict__ dsum) {
+    const size_t mu = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (mu >= Mpad) return;
+    const int sh = assoc_shift(*maxbits);
+    long long d1 = 0, d2 = 0;
+    uint32_t z1 = 0, z2 = 0;
+    const bool nonfinite = ((*maxbits >> 52) & 0x7ffull) == 0x7ffull;
+    if (mu < (size_t)M && !nonfinite) {
+        const double c = msig[mu] * beta[mu];
+        const double d = mave[mu] * c;
+        double q1, q2;
+        split2(__builtin_ldexp(c, sh), q1, q2);
+        z1 = ((uint32_t)(int)(q1 * 0x1p22) + 0x00808080u) ^ 0x00808080u;           // signed base-256 digits
+        z2 = ((uint32_t)(int)(q2 * 0x1p53) + 0x00808080u) ^ 0x00808080u;
+        split2(__builtin_ldexp(d, sh), q1, q2);
+        d1 = (long long)(q1 * 0x1p22);
+        d2 = (long long)(q2 * 0x1p53);
+    }
+    const size_t at = pg_plane_index(mu);
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++) {
+        planes[(size_t)pl * Mpad + at] = (uint8_t)(z1 >> (8 * pl));
+        planes[(size_t)(pl + 4) * Mpad + at] = (uint8_t)(z2 >> (8 * pl));
+    }
+    // sum of D over the block, exact: the two parts as integers (wavefront sum, then one atomic per wavefront)
+    for (int o = 32; o >= 1; o >>= 1) {
+        d1 += ((long long)__shfl_xor((int)(d1 >> 32), o, 64) << 32) + (long long)(unsigned)__shfl_xor((int)d1, o, 64);
+        d2 += ((long long)__shfl_xor((int)(d2 >> 32), o, 64) << 32) + (long long)(unsigned)__shfl_xor((int)d2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && (d1 | d2) != 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(dsum), (unsigned long long)d1);
+        atomicAdd(reinterpret_cast<unsigned long long*>(dsum) + 1, (unsigned long long)d2);
+    }
+}
+
+// 16 x 16 transpose of 2-bit fields across the 16 lanes of a DPP row: in: lane r holds x_r (field f = element (r, f)); out:
+// lane n holds element (f, n) in field f.  Stage d = 8, 4, 2, 1 swaps the off-diagonal d x d blocks with lane r ^ d.
+template <int CTRL> __device__ __forceinline__ uint32_t pg_dpp(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, CTRL, 0xf, 0xf, true);          // every lane of a row has a source: no "old" value needed
+}
+struct PgLane { uint32_t sel8, sel4, keep2, keep1, rot2, rot1; };
+__device__ __forceinline__ PgLane pg_lane_consts(int r) {
+    PgLane c;
+    // stages 8 and 4 move whole bytes (4 fields): one v_perm_b32 of {partner, own} with a per-lane selector
+    c.sel8 = (r & 8) ? 0x03020706u : 0x05040100u;   // hi lanes: {p.b2, p.b3, x.b2, x.b3}; lo lanes: {x.b0, x.b1, p.b0, p.b1}
+    c.sel4 = (r & 4) ? 0x03070105u : 0x06020400u;   // hi lanes: {p.b1, x.b1, p.b3, x.b3}; lo lanes: {x.b0, p.b0, x.b2, p.b2}
+    c.keep2 = (r & 2) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;  c.rot2 = (r & 2) ? 28 : 4;         // rotl by 4 (lo lanes) / rotr by 4 (hi lanes)
+    c.keep1 = (r & 1) ? 0xCCCCCCCCu : 0x33333333u;  c.rot1 = (r & 1) ? 30 : 2;
+    return c;
+}
+__device__ __forceinline__ uint32_t pg_rotl(uint32_t x, uint32_t k) { return __builtin_amdgcn_alignbit(x, x, 32u - k); }
+__device__ __forceinline__ uint32_t pg_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+__device__ __forceinline__ uint32_t pg_transpose16(uint32_t x, const PgLane& c) {
+    uint32_t p;
+    p = pg_dpp<0x141>(pg_dpp<0x140>(x));                  // lane ^ 15 then lane ^ 7: lane ^ 8
+    x = __builtin_amdgcn_perm(p, x, c.sel8);
+    p = pg_dpp<0x1B>(pg_dpp<0x141>(x));                   // lane ^ 7 then lane ^ 3: lane ^ 4
+    x = __builtin_amdgcn_perm(p, x, c.sel4);
+    p = pg_dpp<0x4E>(x);                                  // lane ^ 2
+    x = pg_bfi(c.keep2, x, pg_rotl(p, c.rot2));
+    p = pg_dpp<0xB1>(x);                                  // lane ^ 1
+    x = pg_bfi(c.keep1, x, pg_rotl(p, c.rot1));
+    return x;
+}
+// .bed code -> genotype value in the 2-bit field (00 -> 2, 10 -> 1, 11 -> 0, 01 (missing) -> 3), as sweep.hip's ring
+__device__ __forceinline__ uint32_t pg_recode(uint32_t w) { return (~w & 0xAAAAAAAAu) | ((w ^ (w >> 1)) & 0x55555555u); }
+
+__global__ __launch_bounds__(256) void k_pg_mfma(const uint8_t* __restrict__ bed, size_t stride, int M, const uint8_t* __restrict__ planes,
+                                                 size_t Mpad, unsigned long long* __restrict__ gacc) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_pl[8 * PG_KB];
+    // The workgroup's 64 bytes (256 individuals) of the 256 columns of a super-step, staged through LDS: the loads are issued so
+    // that four lanes cover one column's 64 bytes (16 whole sectors per wave instruction; one lane per column and wavefront --
+    // 64 quarter sectors per instruction -- ran at 2.6 TB/s), the consumers pick their wavefront's 16-byte piece of their column.
+    // Piece p of column c sits at c * 64 + 16 * (p ^ ((c >> 2) & 3)): the 16 lanes of a row read 16 different bank groups.
+    __shared__ __attribute__((aligned(16))) uint8_t s_g[2][256 * 64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 15, kg = lane >> 4;
+    // Workgroups are dispatched round-robin over the 8 XCDs (each with an L2 of its own, 128-byte lines): workgroups that
+    // read neighbouring 64-byte pieces of the same columns must share an XCD, or every line is fetched by two L2s.  Dispatch
+    // index bid = 8 a + c (c = XCD): the eight pieces 8 (8 (a >> 3) + c) + (a & 7) of one 512-byte run go to XCD c, 8 launches apart.
+    const unsigned bid = blockIdx.x, xa = bid >> 3, xc = bid & 7u;
+    const size_t piece = 8 * (8 * (size_t)(xa >> 3) + xc) + (xa & 7u);         // gridDim.x is a multiple of 64
+    const size_t ibyte = piece * 64 + (size_t)wave * 16;                        // this wavefront's 16 bytes (64 individuals) of every column
+    const bool live = ibyte < stride;                                            // the stride is a multiple of 16
+    const size_t mstart = (size_t)blockIdx.y * PG_STAGES * PG_KB;
+    const PgLane lc = pg_lane_consts(n);
+    pg_v4i acc0[4], acc1[4], acc2[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { acc0[t] = pg_v4i{0, 0, 0, 0}; acc1[t] = pg_v4i{0, 0, 0, 0}; acc2[t] = pg_v4i{0, 0, 0, 0}; }
+    constexpr uint32_t M0 = 0x03030303u;
+    for (int st = 0; st < PG_STAGES; st++) {
+        const size_t mb = mstart + (size_t)st * PG_KB;
+        if (mb >= (size_t)M) break;                                               // (uniform)
+        __syncthreads();                                                          // the previous stage's planes are no longer read
+        // eight planes x PG_KB bytes of this stage -> LDS (64 bytes per thread)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int off = (q * 256 + tid) * 16;                                 // byte offset within the 8 x PG_KB block, plane-major
+            const int pl = off / PG_KB, in = off % PG_KB;
+            *reinterpret_cast<uint4*>(s_pl + off) = *reinterpret_cast<const uint4*>(planes + (size_t)pl * Mpad + mb + in);
+        }
+        __syncthreads();
+        // the column bytes of a super-step are requested one super-step ahead and parked in the other LDS buffer at its end
+        const int lpiece = lane & 3;
+        const bool lin = piece * 64 + 16 * (size_t)lpiece < stride;
+        auto request = [&](int ss, uint4 (&dst)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c = 64 * wave + 16 * q + (lane >> 2);
+                const size_t mu = mb + (size_t)ss * 256 + (size_t)c;
+                dst[q] = (lin && mu < (size_t)M) ? *reinterpret_cast<const uint4*>(bed + mu * stride + piece * 64 + 16 * (size_t)lpiece)
+                                                 : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11: a = 0
+            }
+        };
+        auto park = [&](int buf, const uint4 (&src)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c = 64 * wave + 16 * q + (lane >> 2);
+                *reinterpret_cast<uint4*>(s_g[buf] + c * 64 + 16 * (lpiece ^ ((c >> 2) & 3))) = src[q];
+            }
+        };
+        uint4 wn[4];
+        request(0, wn);
+        park(0, wn);
+        __syncthreads();
+#pragma unroll 1
+        for (int ss = 0; ss < PG_KB / 256; ss++) {
+            if (ss + 1 < PG_KB / 256) request(ss + 1, wn);
+            uint4 w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = 64 * kg + 16 * j + n;
+                w[j] = *reinterpret_cast<const uint4*>(s_g[ss & 1] + c * 64 + 16 * (wave ^ ((c >> 2) & 3)));
+            }
+            // operand A: plane row n (rows 8..15 repeat 0..7; their outputs are dropped), this lane group's 16 markers, one chunk per field
+            const uint8_t* ab = s_pl + (n & 7) * PG_KB + ss * 256 + kg * 64;
+            const pg_v4i a0 = *reinterpret_cast<const pg_v4i*>(ab), a1 = *reinterpret_cast<const pg_v4i*>(ab + 16),
+                         a2 = *reinterpret_cast<const pg_v4i*>(ab + 32), a3 = *reinterpret_cast<const pg_v4i*>(ab + 48);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                uint32_t y[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t x = t == 0 ? w[j].x : (t == 1 ? w[j].y : (t == 2 ? w[j].z : w[j].w));
+                    // (a field that reads 3 -- missing genotype -- can only belong to an individual without a phenotype in a block
+                    // that took this path: it spoils that individual's own sums, which k_pg_finish discards)
+                    y[j] = pg_transpose16(pg_recode(x), lc);
+                }
+                const pg_v4i b0 = {(int)(y[0] & M0), (int)(y[1] & M0), (int)(y[2] & M0), (int)(y[3] & M0)};
+                const pg_v4i b1 = {(int)(y[0] & (M0 << 2)), (int)(y[1] & (M0 << 2)), (int)(y[2] & (M0 << 2)), (int)(y[3] & (M0 << 2))};
+                const pg_v4i b2 = {(int)(y[0] & (M0 << 4)), (int)(y[1] & (M0 << 4)), (int)(y[2] & (M0 << 4)), (int)(y[3] & (M0 << 4))};
+                const pg_v4i b3 = {(int)((y[0] >> 6) & M0), (int)((y[1] >> 6) & M0), (int)((y[2] >> 6) & M0), (int)((y[3] >> 6) & M0)};
+                acc0[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc1[t], 0, 0, 0);
+                acc2[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b2, acc2[t], 0, 0, 0);
+                acc0[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, b3, acc0[t], 0, 0, 0);
+            }
+            if (ss + 1 < PG_KB / 256) park((ss + 1) & 1, wn);
+            __syncthreads();
+        }
+    }
+    // C: column n = individual of the tile, rows 4 kg + r = planes.  kg = 0: the four digits of part 1, kg = 1: of part 2.
+    if (live && kg < 2) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            long long sx = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                sx += (long long)(acc0[t][r] + (acc1[t][r] >> 2) + (acc2[t][r] >> 4)) << (8 * r);
+            const size_t ind = 4 * ibyte + 16 * (size_t)t + (size_t)n;
+            if (sx != 0) atomicAdd(gacc + 2 * ind + kg, (unsigned long long)sx);
+        }
+    }
+}
+__global__ void k_pg_finish(const unsigned long long* __restrict__ gacc, const long long* __restrict__ dsum, const uint8_t* __restrict__ namask2,
+                            size_t n4, const unsigned long long* __restrict__ maxbits, double* __restrict__ g) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const bool present = ((namask2[i >> 2] >> (2 * (i & 3))) & 3u) == 3u;
+    const int sh = assoc_shift(*maxbits);
+    const bool nonfinite = ((*maxbits >> 52) & 0x7ffull) == 0x7ffull;
+    const long long t1 = (long long)gacc[2 * i] - dsum[0], t2 = (long long)gacc[2 * i + 1] - dsum[1];
+    const double v = __builtin_ldexp((double)t1 * 0x1p-22 + (double)t2 * 0x1p-53, -sh);
+    g[i] = !present ? 0.0 : (nonfinite ? __longlong_as_double(0x7ff8000000000000ll) : v);
+}
+size_t predict_workspace_bytes(size_t stride, int M) {
+    const size_t Mpad = ((size_t)(M > 0 ? M : 1) + PG_KB - 1) / PG_KB * PG_KB;
+    return 8 * Mpad + 16 * 4 * stride + 64;
+}
+// ws: predict_workspace_bytes(stride, M) bytes.  Every marker of the block must be free of missing genotypes among the phenotyped
+// individuals (the caller checks the marker statistics' flags); g receives 4 * stride doubles.
+hipError_t launch_predict_g_mfma(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* mave,
+                                 const double* msig, const double* beta, double* g, void* ws, hipStream_t st) {
+    if (stride == 0 || M <= 0) return hipSuccess;
+    const size_t Mpad = ((size_t)M + PG_KB - 1) / PG_KB * PG_KB;
+    uint8_t* planes = static_cast<uint8_t*>(ws);
+    unsigned long long* gacc = reinterpret_cast<unsigned long long*>(planes + 8 * Mpad);
+    unsigned long long* maxbits = gacc + 2 * 4 * stride;
+    long long* dsum = reinterpret_cast<long long*>(maxbits + 2);
+    hipError_t e = hipMemsetAsync(gacc, 0, 16 * 4 * stride + 64, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_pg_absmax, dim3(256), dim3(256), 0, st, mave, msig, beta, M, maxbits);
+    hipLaunchKernelGGL(k_pg_planes, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, st, mave, msig, beta, M, Mpad, maxbits, planes, dsum);
+    const unsigned gx = (unsigned)((stride + 63) / 64 + 63) / 64 * 64, gy = (unsigned)(((size_t)M + (size_t)PG_STAGES * PG_KB - 1) / ((size_t)PG_STAGES * PG_KB));
+    hipLaunchKernelGGL(k_pg_mfma, dim3(gx, gy), dim3(256), 0, st, bed, stride, M, planes, Mpad, gacc);
+    hipLaunchKernelGGL(k_pg_finish, dim3((unsigned)((4 * stride + 255) / 256)), dim3(256), 0, st, gacc, dsum, namask2, 4 * stride, maxbits, g);
+    return hipGetLastError();
+}
+
 hipError_t launch_predict_g(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* mave,
                             const double* msig, const double* beta, double* g, hipStream_t st) {
     if (stride == 0 || M <= 0) return hipSuccess;

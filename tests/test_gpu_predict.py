@@ -36,7 +36,10 @@ def test_predict_g_and_assoc_match_the_reference_loops(gpu, name):
         beta[rng.random(case.M) < 0.6] = 0.0                      # most posterior means are exactly 0
         g = ctx.predict_g(0, beta)
         want = orc.predict_g(inp["bed"], mask4, mave, msig, beta)[:case.N]
-        assert np.array_equal(g, want)                            # same operations in the same (marker) order
+        if case.miss == 0.0:                                      # no missing genotypes: the contraction on the matrix cores,
+            assert np.allclose(g, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())   # exact sum rounded once (upstream: no order)
+        else:
+            assert np.array_equal(g, want)                        # same operations in the same (marker) order
         yk = eps[:case.N] - 0.25 * g
         xtx, xty = ctx.assoc(0, yk)
         wxx, wxy = orc.assoc(inp["bed"], mask4, yk)
@@ -80,6 +83,40 @@ def test_assoc_over_many_blocks_and_scales(gpu, scale):
         ok[absent[:3]] = [np.nan, np.inf, 1e300]                 # ... but not where the individual has no phenotype:
         xtx2, xty2 = ctx.assoc(0, ok)                            # those never enter the sums and must not set the scale
         assert np.array_equal(xtx2, xtx) and np.array_equal(xty2, xty)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("scale", [1.0, 2.0 ** 30, 2.0 ** -45])
+def test_predict_g_on_the_matrix_cores(gpu, scale):
+    """gmrm_predict_g for a block without missing genotypes (k_pg_mfma: markers on the K dimension, 2-bit codes transposed
+    across DPP rows, digit planes of msig * beta): several 2048-marker LDS stages with a ragged last one, more than one
+    workgroup column of 32 768 markers, a ragged individual tail, phenotype NAs (their g is 0), effects spanning twelve
+    orders of magnitude with most of them zero, scaled far from unit size.  Against the reference loop's in-order f64 sum:
+    1e-12 of the largest |g| (the kernel's sum is exact and rounded once); and against the in-order device kernel."""
+    import os
+    case = cases.Case("pgm", 20_011, 40_000, 1, 4, 1, 0.0, 600, 21, 1, 20)
+    inp = cases.make_inputs(case)
+    ctx, eps, mask4, nonas, mave, msig = _ctx_with_trait(case, inp)
+    try:
+        rng = np.random.default_rng(4)
+        beta = rng.normal(0.0, 0.01, size=case.M) * 10.0 ** rng.uniform(-9, 3, size=case.M) * scale
+        beta[rng.random(case.M) < 0.7] = 0.0
+        g = ctx.predict_g(0, beta)
+        want = orc.predict_g(inp["bed"], mask4, mave, msig, beta)[:case.N]
+        tol = 1e-12 * np.abs(want).max()
+        assert np.abs(g - want).max() <= tol, (np.abs(g - want).max(), tol)
+        assert not g[inp["isna"][0] != 0].any()
+        os.environ["GMRM_PREDICT_LUT"] = "1"
+        try:
+            g_lut = ctx.predict_g(0, beta)
+        finally:
+            del os.environ["GMRM_PREDICT_LUT"]
+        assert np.array_equal(g_lut, want) and np.abs(g - g_lut).max() <= tol
+        assert not ctx.predict_g(0, np.zeros(case.M)).any()
+        bad = beta.copy()
+        bad[7] = np.nan
+        assert np.isnan(ctx.predict_g(0, bad)[inp["isna"][0] == 0]).all()
     finally:
         ctx.close()
 
