@@ -112,7 +112,14 @@ static int ctx_create_body(gmrm_ctx* c, int device, int N, int M, int Mt, int S,
     HIPCHK(hipGetDeviceProperties(&prop, device));
     c->device = device; c->N = N; c->M = M; c->Mt = Mt; c->S = S; c->T = T;
     c->mbytes = ((size_t)N + 3) / 4;                          // bayes.cpp:776
-    c->stride = (c->mbytes + 15) / 16 * 16;
+    // column stride: a multiple of the L2 line (128 B), so that the 256 R-byte slice a sweep workgroup reads of every column
+    // is made of whole lines -- with a 16-byte multiple a slice straddled a line that the neighbouring workgroup (another
+    // XCD, another L2) fetched as well (GMRM_STRIDE_ALIGN=16 restores that for A/B runs)
+    {
+        size_t al = 128;
+        if (const char* e = std::getenv("GMRM_STRIDE_ALIGN")) { const int v = std::atoi(e); if (v == 16 || v == 64 || v == 128 || v == 256) al = (size_t)v; }
+        c->stride = (c->mbytes + al - 1) / al * al;
+    }
     c->num_cu = prop.multiProcessorCount;
     // Phenotypes are independent chains.  `conc` of them sweep side by side (each persistent launch
     // needs one CU per workgroup): the largest count for which a chain still fits num_cu / conc
