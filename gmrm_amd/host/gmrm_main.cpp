@@ -234,16 +234,21 @@ void cross_bim_files(const Opts& opt, std::vector<std::string>& rsid, std::unord
 // Bayes::predict (bayes.cpp:16-284) on one GPU = one rank: posterior-mean effects from <stem>.bet,
 // g = Z beta (k_predict_g), leave-other-ranks-out correction of y (nothing to leave out with one
 // rank, bayes.cpp:141-142), per-marker OLS beta / t / se / p (k_assoc + host arithmetic), <stem>.mlma.
-void run_predict(const Opts& opt, gmrm_ctx* ctx, int N, int M, const std::vector<std::string>& stems,
-                 const std::vector<std::vector<double>>& eps0, const std::vector<int>& nonas) {
+// Bayes::predict (bayes.cpp:16-284) over the marker shards (upstream: MPI tasks): every shard computes the genetic values
+// of ITS markers (g_k), the shards' g_k are summed (MPI_Allreduce, bayes.cpp:136), every shard removes the OTHER shards'
+// markers from the phenotype (y_k = y - (g - g_k), bayes.cpp:141-142), tests its own markers against that and writes its
+// records behind those of the shards before it (bayes.cpp:246-252).
+void run_predict(const Opts& opt, const std::vector<gmrm_ctx*>& ctxs, const std::vector<int>& S_, const std::vector<int>& M_, int N, int Mt,
+                 const std::vector<std::string>& stems, const std::vector<std::vector<double>>& eps0, const std::vector<int>& nonas) {
     const double ts = now();
+    const int nsh = (int)ctxs.size();
     std::vector<std::string> rsid;
     std::unordered_map<std::string, int> refrsid;
     cross_bim_files(opt, rsid, refrsid);
-    if ((int)rsid.size() < M) fatal("FATAL  : bim file has fewer rows than markers in the dim file.");
+    if ((int)rsid.size() < Mt) fatal("FATAL  : bim file has fewer rows than markers in the dim file.");
     const int T = (int)stems.size();
     for (int t = 0; t < T; t++) {
-        need(gmrm_marker_stats(ctx, t), "gmrm_marker_stats");
+        for (int r = 0; r < nsh; r++) need(gmrm_marker_stats(ctxs[r], t), "gmrm_marker_stats");
         const std::string base = opt.out_dir.empty() ? stems[t] : opt.out_dir + "/" + stems[t];
         const std::string inbet = replace_ext(base, ".bet"), outmlma = base + ".mlma";   // phenotype.cpp:115-127
         unlink(outmlma.c_str());                                                         // bayes.cpp:33
@@ -272,39 +277,51 @@ void run_predict(const Opts& opt, gmrm_ctx* ctx, int N, int M, const std::vector
         for (unsigned j = 0; j < Mtot_; j++) beta_sum[j] /= double(niter);
         close(fb);
 
-        // bayes.cpp:93-122.  beta_sum is indexed by the row of the CURRENT bim (mglo), as upstream does.
-        std::vector<double> beta_local(M, 0.0);
-        std::vector<int> rm(M, -1);
-        for (int m = 0; m < M; m++) {
-            auto f = refrsid.find(rsid[m]);
-            if (f == refrsid.end()) continue;
-            rm[m] = f->second;
-            if ((unsigned)m >= Mtot_) fatal("FATAL  : marker row beyond the .bet file's Mtot (upstream reads out of bounds here).");
-            beta_local[m] = beta_sum[m];
+        // bayes.cpp:93-122 per shard.  beta_sum is indexed by the row of the CURRENT bim (mglo), as upstream does.
+        std::vector<int> rm(Mt, -1);
+        std::vector<std::vector<double>> g_k(nsh, std::vector<double>(N));
+        for (int r = 0; r < nsh; r++) {
+            std::vector<double> beta_local(M_[r], 0.0);
+            for (int m = 0; m < M_[r]; m++) {
+                const int mglo = S_[r] + m;
+                auto f = refrsid.find(rsid[mglo]);
+                if (f == refrsid.end()) continue;
+                rm[mglo] = f->second;
+                if ((unsigned)mglo >= Mtot_) fatal("FATAL  : marker row beyond the .bet file's Mtot (upstream reads out of bounds here).");
+                beta_local[m] = beta_sum[mglo];
+            }
+            need(gmrm_predict_g(ctxs[r], t, beta_local.data(), g_k[r].data()), "gmrm_predict_g");
         }
-        std::vector<double> g_k(N), y_k(eps0[t].begin(), eps0[t].begin() + N);
-        need(gmrm_predict_g(ctx, t, beta_local.data(), g_k.data()), "gmrm_predict_g");
-        const std::vector<double>& g = g_k;                                              // MPI_Allreduce over one rank
-        for (int i = 0; i < N; i++) y_k[i] -= (g[i] - g_k[i]);                           // bayes.cpp:141-142
-        double sigma = 0.0;
-        for (int i = 0; i < N; i++) sigma += y_k[i] * y_k[i];
-        sigma /= nonas[t];
-        std::vector<double> xtx(M), xty(M);
-        need(gmrm_assoc(ctx, t, y_k.data(), xtx.data(), xty.data()), "gmrm_assoc");
+        std::vector<double> g(N, 0.0);                                                   // MPI_Allreduce(SUM), bayes.cpp:136: shard order
+        for (int r = 0; r < nsh; r++)
+            for (int i = 0; i < N; i++) g[i] += g_k[r][i];
         const int LLEN = 123 + 1;
-        std::vector<char> todump((size_t)LLEN * (size_t)std::max(1, M));
-        int n_rem = 0;
-        for (int m = 0; m < M; m++) {
-            if (rm[m] < 0) { printf("WARNING: marker id %s excluded -- no match\n", rsid[m].c_str()); n_rem++; continue; }
-            const double beta = xty[m] / xtx[m];                                         // bayes.cpp:198-205
-            const double tdist = xty[m] / sqrt(sigma * xtx[m]);
-            const double se = beta / tdist;
-            const double pval = 1.0 - erf(sqrt(tdist * tdist * 0.5));                   // 1 - gamma_p(1/2, t^2/2)
-            const int cx = snprintf(&todump[(size_t)(m - n_rem) * (LLEN - 1)], LLEN, "%20s %8d %8d %20.15f %20.15f %20.15f %20.15f\n",
-                                    rsid[m].c_str(), m, rm[m], beta, tdist, se, pval);
-            if (cx < 0 || cx >= LLEN) fatal("FATAL  : .mlma record longer than 123 bytes (marker id over 20 characters or a value over 4 integer digits).");   // bayes.cpp:235 assert
+        off_t at = 0;                                                                    // records of the shards before this one, bayes.cpp:246-252
+        for (int r = 0; r < nsh; r++) {
+            const int M = M_[r];
+            std::vector<double> y_k(eps0[t].begin(), eps0[t].begin() + N);
+            for (int i = 0; i < N; i++) y_k[i] -= (g[i] - g_k[r][i]);                    // bayes.cpp:141-142
+            double sigma = 0.0;
+            for (int i = 0; i < N; i++) sigma += y_k[i] * y_k[i];
+            sigma /= nonas[t];
+            std::vector<double> xtx(std::max(1, M)), xty(std::max(1, M));
+            need(gmrm_assoc(ctxs[r], t, y_k.data(), xtx.data(), xty.data()), "gmrm_assoc");
+            std::vector<char> todump((size_t)LLEN * (size_t)std::max(1, M));
+            int n_rem = 0;
+            for (int m = 0; m < M; m++) {
+                const int mglo = S_[r] + m;
+                if (rm[mglo] < 0) { printf("WARNING: marker id %s excluded -- no match\n", rsid[mglo].c_str()); n_rem++; continue; }
+                const double beta = xty[m] / xtx[m];                                     // bayes.cpp:198-205
+                const double tdist = xty[m] / sqrt(sigma * xtx[m]);
+                const double se = beta / tdist;
+                const double pval = 1.0 - erf(sqrt(tdist * tdist * 0.5));               // 1 - gamma_p(1/2, t^2/2)
+                const int cx = snprintf(&todump[(size_t)(m - n_rem) * (LLEN - 1)], LLEN, "%20s %8d %8d %20.15f %20.15f %20.15f %20.15f\n",
+                                        rsid[mglo].c_str(), mglo, rm[mglo], beta, tdist, se, pval);
+                if (cx < 0 || cx >= LLEN) fatal("FATAL  : .mlma record longer than 123 bytes (marker id over 20 characters or a value over 4 integer digits).");   // bayes.cpp:235 assert
+            }
+            if (M - n_rem > 0) fm.put(todump.data(), (size_t)(LLEN - 1) * (size_t)(M - n_rem), at);
+            at += (off_t)(LLEN - 1) * (off_t)(M - n_rem);
         }
-        if (M - n_rem > 0) fm.put(todump.data(), (size_t)(LLEN - 1) * (size_t)(M - n_rem), 0);
         close(fm.fd);
     }
     printf("INFO   : Time to compute the predictions: %.2f seconds.\n", now() - ts);
@@ -342,7 +359,6 @@ int main(int argc, char** argv) {
     // bayes.cpp:903-925): what MPI ranks are upstream.  `ctx` / `smp` below are shard 0.
     std::vector<int> devs = opt.devices.empty() ? std::vector<int>{opt.device} : opt.devices;
     const int nsh = (int)devs.size();
-    if (opt.predict && nsh > 1) fatal("FATAL  : --predict runs on one GPU in this build.");
     std::vector<int> S_(nsh), M_(nsh);
     {
         const int modu = Mt % nsh, size = Mt / nsh, Mm = modu != 0 ? size + 1 : size;
@@ -354,7 +370,6 @@ int main(int argc, char** argv) {
     }
     std::vector<gmrm_ctx*> ctxs(nsh, nullptr);
     for (int r = 0; r < nsh; r++) need(gmrm_ctx_create(&ctxs[r], devs[r], N, M_[r], Mt, S_[r], T), "gmrm_ctx_create");
-    gmrm_ctx* ctx = ctxs[0];
 
     // bayes.cpp:867-900: marker-major block after 3 magic bytes (validated by the library; upstream skips
     // them unchecked).  Parallel chunked pread -> pinned ring -> copy engine, gmrm_amd/csrc/ingest.cpp.
@@ -407,9 +422,9 @@ int main(int argc, char** argv) {
     printf("INFO   : output directory: %s\n", opt.out_dir.c_str());
     if (opt.predict) {                                                       // main.cpp:15-16, bayes.cpp:794
         const double ts = now();
-        run_predict(opt, ctx, N, Mt, stems, eps0, nonas_t);
+        run_predict(opt, ctxs, S_, M_, N, Mt, stems, eps0, nonas_t);
         (void)ts;
-        gmrm_ctx_destroy(ctx);
+        for (int r = 0; r < nsh; r++) gmrm_ctx_destroy(ctxs[r]);
         return 0;
     }
 

@@ -172,3 +172,62 @@ def test_cli_predict_writes_the_reference_mlma_records(gpu, tmp_path):
             assert np.allclose([float(x) for x in f[3:7]], [beta, tdist, se, pval], rtol=0, atol=2e-12)
             if k < 3:                                             # the record layout itself, byte for byte, from its own numbers
                 assert got.encode() == orc.mlma_line(ids[m], m, refpos[ids[m]], *[float(x) for x in f[3:7]])
+
+
+def test_cli_predict_over_marker_shards(gpu, tmp_path):
+    """--predict with --devices 0,0 (two marker shards; upstream: two MPI tasks, bayes.cpp:16-284): every shard computes g
+    for its block, the sum is shared (MPI_Allreduce, :136), every shard tests its own markers against the phenotype minus
+    the OTHER shard's genetic values (:141-142) and writes its records behind the first shard's (:246-252)."""
+    assert BIN.exists(), "bin/gmrm_hip not built (python __graft_entry__.py)"
+    from gmrm_amd.api import block_of_markers
+    case = cases.CASE_BY_NAME["small"]
+    inp = cases.make_inputs(case)
+    inp["cva"] = np.array([[float(f"{v:.5f}") for v in row] for row in inp["cva"]])
+    phens = _write_inputs(tmp_path, case, inp)
+    out = tmp_path / "out"
+    common = ["--bed-file", str(tmp_path / "t.bed"), "--dim-file", str(tmp_path / "t.dim"),
+              "--phen-files", ",".join(str(p) for p in phens), "--out-dir", str(out)]
+    r = subprocess.run([str(BIN), *common, "--group-index-file", str(tmp_path / "t.gri"), "--group-mixture-file", str(tmp_path / "t.grm"),
+                        "--seed", str(case.seed), "--iterations", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ids = [f"rs{1000 + i}" for i in range(case.M)]
+    (tmp_path / "cur.bim").write_text("".join(f"1 {rid} 0 {i + 1} A C\n" for i, rid in enumerate(ids)))
+    (tmp_path / "ref.bim").write_text("".join(f"1 {rid} 0 {i + 1} A C\n" for i, rid in enumerate(ids)))
+    r = subprocess.run([str(BIN), *common, "--predict", "--devices", "0,0", "--bim-file", str(tmp_path / "cur.bim"), "--ref-bim-file", str(tmp_path / "ref.bim")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    eps, mask4, nonas = orc.phen_prepare(inp["y"][0], inp["isna"][0])
+    raw = (out / "trait0.bet").read_bytes()
+    M = struct.unpack("<I", raw[:4])[0]
+    rec = 4 + 8 * M
+    beta_sum = np.zeros(M)
+    for k in range(4):
+        beta_sum = beta_sum + np.frombuffer(raw[4 + k * rec + 4:4 + (k + 1) * rec], dtype="<f8")
+    beta_sum = beta_sum / 4.0
+    L = orc.lib()
+    n4 = cases.im4_of(case.N)
+    mave, msig = np.empty(case.M), np.empty(case.M)
+    L.orc_marker_stats_canon(inp["bed"].ctypes.data_as(orc.c_u8_p), case.N, case.M, n4, mask4.ctypes.data_as(orc.c_u8_p), nonas,
+                             mave.ctypes.data_as(orc.c_double_p), msig.ctypes.data_as(orc.c_double_p))
+    lines = (out / "trait0.mlma").read_bytes()
+    assert len(lines) == 123 * case.M
+    gk = []
+    for rnk in range(2):
+        S, Ml, _ = block_of_markers(case.M, 2, rnk)
+        gk.append(orc.predict_g(inp["bed"][S:S + Ml], mask4, mave[S:S + Ml], msig[S:S + Ml], beta_sum[S:S + Ml])[:case.N])
+    g = gk[0] + gk[1]
+    for rnk in range(2):
+        S, Ml, _ = block_of_markers(case.M, 2, rnk)
+        yk = eps[:case.N] - (g - gk[rnk])
+        sigma = float(np.sum(yk * yk)) / nonas
+        xtx, xty = orc.assoc(inp["bed"][S:S + Ml], mask4, yk)
+        for m in (0, 1, Ml // 2, Ml - 1):
+            f = lines[123 * (S + m):123 * (S + m + 1)].decode().split()
+            assert f[0] == ids[S + m] and int(f[1]) == S + m and int(f[2]) == S + m
+            want = orc.mlma_stats(xtx[m], xty[m], sigma)
+            assert np.allclose([float(x) for x in f[3:7]], want, rtol=1e-9, atol=1e-11), (rnk, m, f, want)
+    # and it differs from the one-shard answer only through y_k: with one shard nothing is removed from y
+    r1 = subprocess.run([str(BIN), *common, "--predict", "--bim-file", str(tmp_path / "cur.bim"), "--ref-bim-file", str(tmp_path / "ref.bim")],
+                        capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0
+    assert (out / "trait0.mlma").read_bytes() != lines
