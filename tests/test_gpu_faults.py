@@ -153,3 +153,41 @@ def test_checkpoint_with_a_damaged_visit_order_is_refused(gpu, tmp_path):
     assert smp.load(ck) == 1                                               # the intact file still loads
     smp.close()
     ctx.close()
+
+
+def _big_grid_worker(rank, outdir, lock_dir):
+    """One of two PROCESSES on device 0, each with a sweep that needs (nearly) every compute unit."""
+    import os
+    os.environ["GMRM_LOCK_DIR"] = lock_dir
+    os.environ["GMRM_SPIN_TIMEOUT_MS"] = "1500"
+    import numpy as np
+    import gmrm_amd
+    N, M = 500_000, 1500
+    rng = np.random.default_rng(100 + rank)
+    ctx = gmrm_amd.Context(N, M)
+    ctx.synth_bed(171014 + rank, 0.4, 0.0)
+    eps, mask4, nonas = gmrm_amd.prepare_phenotype(rng.normal(size=N), np.zeros(N, dtype=np.uint8))
+    ctx.upload_trait(0, eps, mask4, nonas)
+    ctx.compute_markers_statistics(0)
+    smp = gmrm_amd.Sampler(ctx, 7 + rank, np.array([[0.0, 0.0001, 0.001, 0.01]]), np.zeros(M, dtype=np.int32))
+    ms = []
+    for it in range(1, 9):
+        smp.iterate(it)                                            # GMRM_EKERNEL (spin timeout) would raise here
+        ms.append(smp.hyper(0).sweep_device_ms)
+    np.save(f"{outdir}/ok{rank}.npy", np.array(ms))
+    smp.close()
+    ctx.close()
+
+
+def test_two_processes_with_full_device_sweeps_alternate(gpu, tmp_path):
+    """the in-flight accounting is per process.  Two processes whose sweeps each need 245 of the 256
+    compute units cannot be co-resident: interleaved, their workgroups would wait for each other until the spin timeout.
+    Such sweeps take a per-device advisory lock from launch to finish (capi.cpp, devlock_acquire) and alternate."""
+    import torch.multiprocessing as mp
+    g = gmrm_amd.Context(500_000, 8).geometry()
+    assert 2 * g["W"] * g["conc"] > g["max_resident_wg"]            # the geometry the lock is for
+    mp.spawn(_big_grid_worker, args=(str(tmp_path), str(tmp_path)), nprocs=2, join=True)
+    for rank in (0, 1):
+        ms = np.load(tmp_path / f"ok{rank}.npy")
+        assert len(ms) == 8 and (ms > 0).all() and ms.max() < 1000.0
+    assert any(p.name.startswith("gmrm_hip_") and p.name.endswith(".lock") for p in tmp_path.iterdir())
