@@ -9,6 +9,13 @@ disassembles every k_sweep instantiation, rebuilds its basic blocks and proves b
 that every instruction naming one of those AGPRs (other than the loads themselves) is reached only
 through an `s_waitcnt vmcnt(0)` issued after the last such load, on every path.
 
+The same hazard one level down: phase A stages its MFMA operands with `ds_read_b128` issued through inline
+asm (stage_read) one super-step ahead of their use and waits with a hand-counted `s_waitcnt lgkmcnt(n)` (stage_wait).
+check_stage() replays every basic block: it keeps the in-order queue of LDS operations in flight (LDS returns in
+order, so `lgkmcnt(n)` retires all but the last n), marks the destination VGPRs of the asm reads as pending until a
+wait retires them, and fails if any instruction names a pending register, if a scalar memory load (out of order
+with respect to LDS) is in flight at a counted wait, or if a block ends with such a register pending.
+
   python tools/check_prefetch_regs.py            # compiles gmrm_amd/csrc/sweep.hip to assembly (hipcc -S)
   python tools/check_prefetch_regs.py file.s     # checks an existing assembly file
 Exit code 0 = invariant holds for every instantiation.
@@ -47,6 +54,91 @@ def kernels(asm):
                 cur = None
             else:
                 cur.append(ln)
+
+
+VRANGE = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+LGKM = re.compile(r"lgkmcnt\((\d+)\)")
+
+
+def vgprs(text):
+    out = set()
+    for m in VRANGE.finditer(text):
+        if m.group(1) is not None:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def check_stage(name, lines):
+    """The staged LDS reads of phase A (see the module docstring).  Straight-line replay per basic block."""
+    problems, in_asm = [], False
+    queue = []                 # LDS operations in flight, oldest first: the set of asm-read destination VGPRs (or an empty set)
+    smem = 0                   # scalar loads in flight (they share lgkmcnt and return out of order)
+    n_reads = n_waits = 0
+
+    def pending():
+        out = set()
+        for q in queue:
+            out |= q
+        return out
+
+    for ln in lines:
+        raw = ln.strip()
+        if raw.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if raw.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        s = ln.split(";")[0].strip()
+        if not s:
+            continue
+        if re.match(r"^\.LBB\d+_\d+:", s) or s.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+            if pending():
+                problems.append(f"{name}: staged LDS read register(s) {sorted(pending())[:4]}.. still pending at a basic-block boundary (`{s}`)")
+            queue, smem = [], 0                                   # (compiler-issued operations are the compiler's business)
+            continue
+        if s.startswith(".") or s.endswith(":"):
+            continue
+        if s.startswith("s_waitcnt"):
+            m = LGKM.search(s)
+            if m is None and "lgkmcnt" not in s and not re.match(r"^s_waitcnt\s+(0x[0-9a-f]+|\d+)$", s):
+                continue                                          # vmcnt / expcnt only
+            keep = int(m.group(1)) if m else 0                    # a raw immediate: treated as lgkmcnt(0) only if it says so below
+            if m is None:
+                imm = int(s.split()[1], 0)
+                keep = (imm >> 8) & 0xF
+            if pending():
+                n_waits += 1
+                if smem and keep:
+                    problems.append(f"{name}: `{s}` counts LDS reads while {smem} scalar load(s) are in flight (they return out of order)")
+            while len(queue) > keep:
+                queue.pop(0)
+            if keep == 0:
+                smem = 0
+            continue
+        if s.startswith(("s_load_", "s_buffer_load_", "s_scratch_load_")):
+            smem += 1
+            continue
+        if in_asm and s.startswith("ds_read_b128"):
+            dst = vgprs(s.split(",")[0])
+            touched = vgprs(s.split(",", 1)[1]) & pending()
+            if touched:
+                problems.append(f"{name}: `{s}` addresses through pending staged register(s) {sorted(touched)}")
+            queue.append(dst)
+            n_reads += 1
+            continue
+        touched = vgprs(s) & pending()
+        if touched:
+            problems.append(f"{name}: `{s}` touches staged LDS read register(s) {sorted(touched)[:4]}.. before the wait that retires them")
+        if s.startswith("ds_") or s.startswith("buffer_load") and " lds" in s:
+            queue.append(set())                                   # any other LDS operation takes a place in the in-order queue
+    if n_reads == 0:
+        problems.append(f"{name}: no staged ds_read_b128 found (did phase A change?)")
+    if not problems:
+        print(f"ok  {name}: {n_reads} staged LDS reads, retired by {n_waits} counted waits before any use")
+    return problems
 
 
 def check_kernel(name, lines):
@@ -151,6 +243,7 @@ def main():
     for name, lines in kernels(asm):
         n += 1
         bad += check_kernel(name, lines)
+        bad += check_stage(name, lines)
     if n == 0:
         bad.append("no gm::k_sweep instantiation found in the assembly")
     for b in bad:
