@@ -532,12 +532,12 @@ int gmrm_predict_g(gmrm_ctx* c, int t, const double* beta_local, double* g) {
         if ((e = hipMemset(d_g, 0, 4 * c->stride * sizeof(double))) != hipSuccess) break;
         if ((e = hipMemcpy(d_beta, beta_local, (size_t)c->M * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) break;
         if ((e = hipDeviceSynchronize()) != hipSuccess) break;
-        // No marker of the block with a missing genotype among the phenotyped individuals (the marker statistics' flags): the
-        // contraction over markers runs on the matrix cores, exact sum rounded once (ops.hip, k_pg_mfma); otherwise the
-        // in-order f64 kernel.  GMRM_PREDICT_LUT=1 forces the latter.
-        if (tr.miss_mode == 0 && !std::getenv("GMRM_PREDICT_LUT")) {
+        // The contraction over markers runs on the matrix cores, exact sum rounded once (ops.hip, k_pg_mfma); a block with
+        // missing genotypes among the phenotyped individuals (the marker statistics' flags) takes the variant with the
+        // indicator planes.  GMRM_PREDICT_LUT=1 forces the in-order f64 kernel.
+        if (!std::getenv("GMRM_PREDICT_LUT")) {
             if ((e = hipMalloc(&d_ws, predict_workspace_bytes(c->stride, c->M))) != hipSuccess) break;
-            if ((e = launch_predict_g_mfma(c->bed, tr.namask2, c->stride, c->M, tr.mave, tr.msig, d_beta, d_g, d_ws, tr.stream)) != hipSuccess) break;
+            if ((e = launch_predict_g_mfma(c->bed, tr.namask2, c->stride, c->M, tr.mave, tr.msig, d_beta, d_g, d_ws, tr.miss_mode != 0, tr.stream)) != hipSuccess) break;
         } else if ((e = launch_predict_g(c->bed, tr.namask2, c->stride, c->M, tr.mave, tr.msig, d_beta, d_g, tr.stream)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(tr.stream)) != hipSuccess) break;
         e = hipMemcpy(g, d_g, (size_t)c->N * sizeof(double), hipMemcpyDeviceToHost);

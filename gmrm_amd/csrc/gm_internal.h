@@ -80,7 +80,7 @@ hipError_t launch_predict_g(const uint8_t* bed, const uint8_t* namask2, size_t s
                             const double* msig, const double* beta, double* g, hipStream_t st);
 size_t predict_workspace_bytes(size_t stride, int M);
 hipError_t launch_predict_g_mfma(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* mave,
-                                 const double* msig, const double* beta, double* g, void* ws, hipStream_t st);
+                                 const double* msig, const double* beta, double* g, void* ws, int dirty, hipStream_t st);
 size_t assoc_workspace_bytes(size_t stride);
 hipError_t launch_assoc(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* y,
                         double* xtx, double* xty, void* ws, hipStream_t st);

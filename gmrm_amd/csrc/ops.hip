@@ -619,8 +619,11 @@ hipError_t launch_selftest(int op, const double* x, double* y, int n, hipStream_
 // markers.  Four such dwords are the lane's 16 bytes of operand B; as in the sweep kernel, MFMA i takes field i of every
 // byte (one v_and per register) and the factor 4^i is divided out of that field's accumulator.  For a block whose markers
 // have no missing genotype among the phenotyped individuals b = 1 wherever the output is kept, so
-// g_i = sum_m a_im C_m - sum_m D_m with the second sum one exact constant (k_pg_planes).  Blocks with missing genotypes
-// go through k_predict_g<BW> above (same values to 1e-12, in-order f64 sum).
+// g_i = sum_m a_im C_m - sum_m D_m with the second sum one exact constant (k_pg_planes).  A block with missing genotypes
+// (DIRTY) adds the term of the missing-genotype indicator z_im = 1 - b_im:  g_i = sum_m a'_im C_m - sum_m D_m + sum_m z_im D_m
+// (a' = a with 0 for a missing genotype): operand A carries the digit planes of D_m in rows 8..15 next to those of C_m in
+// rows 0..7, a second MFMA set takes the indicator fields as operand B, and of each set the rows of the other are dropped.
+// k_predict_g<BW> above (same values to 1e-12, in-order f64 sum) remains as the reference kernel (GMRM_PREDICT_LUT=1).
 constexpr int PG_KB = 2048;                         // markers per LDS stage (8 super-steps of 256)
 constexpr int PG_STAGES = 16;                       // stages per workgroup: 32 768 markers
 typedef int pg_v4i __attribute__((ext_vector_type(4)));
@@ -649,12 +652,12 @@ __device__ __forceinline__ size_t pg_plane_index(size_t mu) {
 }
 __global__ void k_pg_planes(const double* __restrict__ mave, const double* __restrict__ msig, const double* __restrict__ beta,
                             int M, size_t Mpad, const unsigned long long* __restrict__ maxbits, uint8_t* __restrict__ planes,
-                            long long* __restrict__ dsum) {
+                            long long* __restrict__ dsum, int dirty) {
     const size_t mu = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (mu >= Mpad) return;
     const int sh = assoc_shift(*maxbits);
     long long d1 = 0, d2 = 0;
-    uint32_t z1 = 0, z2 = 0;
+    uint32_t z1 = 0, z2 = 0, y1 = 0, y2 = 0;
     const bool nonfinite = ((*maxbits >> 52) & 0x7ffull) == 0x7ffull;
     if (mu < (size_t)M && !nonfinite) {
         const double c = msig[mu] * beta[mu];
@@ -666,12 +669,18 @@ __global__ void k_pg_planes(const double* __restrict__ mave, const double* __res
         split2(__builtin_ldexp(d, sh), q1, q2);
         d1 = (long long)(q1 * 0x1p22);
         d2 = (long long)(q2 * 0x1p53);
+        y1 = ((uint32_t)(int)d1 + 0x00808080u) ^ 0x00808080u;
+        y2 = ((uint32_t)(int)d2 + 0x00808080u) ^ 0x00808080u;
     }
     const size_t at = pg_plane_index(mu);
 #pragma unroll
     for (int pl = 0; pl < 4; pl++) {
         planes[(size_t)pl * Mpad + at] = (uint8_t)(z1 >> (8 * pl));
         planes[(size_t)(pl + 4) * Mpad + at] = (uint8_t)(z2 >> (8 * pl));
+        if (dirty) {
+            planes[(size_t)(pl + 8) * Mpad + at] = (uint8_t)(y1 >> (8 * pl));
+            planes[(size_t)(pl + 12) * Mpad + at] = (uint8_t)(y2 >> (8 * pl));
+        }
     }
     // sum of D over the block, exact: the two parts as integers (wavefront sum, then one atomic per wavefront)
     for (int o = 32; o >= 1; o >>= 1) {
@@ -716,9 +725,11 @@ __device__ __forceinline__ uint32_t pg_transpose16(uint32_t x, const PgLane& c) 
 // .bed code -> genotype value in the 2-bit field (00 -> 2, 10 -> 1, 11 -> 0, 01 (missing) -> 3), as sweep.hip's ring
 __device__ __forceinline__ uint32_t pg_recode(uint32_t w) { return (~w & 0xAAAAAAAAu) | ((w ^ (w >> 1)) & 0x55555555u); }
 
+template <bool DIRTY>
 __global__ __launch_bounds__(256) void k_pg_mfma(const uint8_t* __restrict__ bed, size_t stride, int M, const uint8_t* __restrict__ planes,
                                                  size_t Mpad, unsigned long long* __restrict__ gacc) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_pl[8 * PG_KB];
+    constexpr int NPL = DIRTY ? 16 : 8;             // digit planes staged per marker: C (and D)
+    __shared__ __attribute__((aligned(16))) uint8_t s_pl[NPL * PG_KB];
     // The workgroup's 64 bytes (256 individuals) of the 256 columns of a super-step, staged through LDS: the loads are issued so
     // that four lanes cover one column's 64 bytes (16 whole sectors per wave instruction; one lane per column and wavefront --
     // 64 quarter sectors per instruction -- ran at 2.6 TB/s), the consumers pick their wavefront's 16-byte piece of their column.
@@ -735,17 +746,20 @@ __global__ __launch_bounds__(256) void k_pg_mfma(const uint8_t* __restrict__ bed
     const size_t mstart = (size_t)blockIdx.y * PG_STAGES * PG_KB;
     const PgLane lc = pg_lane_consts(n);
     pg_v4i acc0[4], acc1[4], acc2[4];
+    pg_v4i zcc0[DIRTY ? 4 : 1], zcc1[DIRTY ? 4 : 1], zcc2[DIRTY ? 4 : 1];
 #pragma unroll
     for (int t = 0; t < 4; t++) { acc0[t] = pg_v4i{0, 0, 0, 0}; acc1[t] = pg_v4i{0, 0, 0, 0}; acc2[t] = pg_v4i{0, 0, 0, 0}; }
-    constexpr uint32_t M0 = 0x03030303u;
+#pragma unroll
+    for (int t = 0; t < (DIRTY ? 4 : 1); t++) { zcc0[t] = pg_v4i{0, 0, 0, 0}; zcc1[t] = pg_v4i{0, 0, 0, 0}; zcc2[t] = pg_v4i{0, 0, 0, 0}; }
+    constexpr uint32_t M0 = 0x03030303u, M1 = 0x01010101u;
     for (int st = 0; st < PG_STAGES; st++) {
         const size_t mb = mstart + (size_t)st * PG_KB;
         if (mb >= (size_t)M) break;                                               // (uniform)
         __syncthreads();                                                          // the previous stage's planes are no longer read
-        // eight planes x PG_KB bytes of this stage -> LDS (64 bytes per thread)
+        // NPL planes x PG_KB bytes of this stage -> LDS (64 or 128 bytes per thread)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int off = (q * 256 + tid) * 16;                                 // byte offset within the 8 x PG_KB block, plane-major
+        for (int q = 0; q < NPL / 2; q++) {
+            const int off = (q * 256 + tid) * 16;                                 // byte offset within the NPL x PG_KB block, plane-major
             const int pl = off / PG_KB, in = off % PG_KB;
             *reinterpret_cast<uint4*>(s_pl + off) = *reinterpret_cast<const uint4*>(planes + (size_t)pl * Mpad + mb + in);
         }
@@ -782,8 +796,9 @@ __global__ __launch_bounds__(256) void k_pg_mfma(const uint8_t* __restrict__ bed
                 const int c = 64 * kg + 16 * j + n;
                 w[j] = *reinterpret_cast<const uint4*>(s_g[ss & 1] + c * 64 + 16 * (wave ^ ((c >> 2) & 3)));
             }
-            // operand A: plane row n (rows 8..15 repeat 0..7; their outputs are dropped), this lane group's 16 markers, one chunk per field
-            const uint8_t* ab = s_pl + (n & 7) * PG_KB + ss * 256 + kg * 64;
+            // operand A: plane row n (clean blocks: rows 8..15 repeat 0..7 and their outputs are dropped), this lane group's 16 markers,
+            // one chunk per field
+            const uint8_t* ab = s_pl + (DIRTY ? n : (n & 7)) * PG_KB + ss * 256 + kg * 64;
             const pg_v4i a0 = *reinterpret_cast<const pg_v4i*>(ab), a1 = *reinterpret_cast<const pg_v4i*>(ab + 16),
                          a2 = *reinterpret_cast<const pg_v4i*>(ab + 32), a3 = *reinterpret_cast<const pg_v4i*>(ab + 48);
 #pragma unroll
@@ -792,9 +807,25 @@ __global__ __launch_bounds__(256) void k_pg_mfma(const uint8_t* __restrict__ bed
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t x = t == 0 ? w[j].x : (t == 1 ? w[j].y : (t == 2 ? w[j].z : w[j].w));
-                    // (a field that reads 3 -- missing genotype -- can only belong to an individual without a phenotype in a block
-                    // that took this path: it spoils that individual's own sums, which k_pg_finish discards)
+                    // (clean blocks: a field that reads 3 -- missing genotype -- can only belong to an individual without a phenotype:
+                    // it spoils that individual's own sums, which k_pg_finish discards)
                     y[j] = pg_transpose16(pg_recode(x), lc);
+                }
+                if constexpr (DIRTY) {
+                    uint32_t z[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        z[j] = y[j] & (y[j] >> 1) & 0x55555555u;                    // 1 in the low bit of every field that reads 3
+                        y[j] &= ~(z[j] | (z[j] << 1));                               // a' = 0 there
+                    }
+                    const pg_v4i z0 = {(int)(z[0] & M1), (int)(z[1] & M1), (int)(z[2] & M1), (int)(z[3] & M1)};
+                    const pg_v4i z1 = {(int)(z[0] & (M1 << 2)), (int)(z[1] & (M1 << 2)), (int)(z[2] & (M1 << 2)), (int)(z[3] & (M1 << 2))};
+                    const pg_v4i z2 = {(int)(z[0] & (M1 << 4)), (int)(z[1] & (M1 << 4)), (int)(z[2] & (M1 << 4)), (int)(z[3] & (M1 << 4))};
+                    const pg_v4i z3 = {(int)((z[0] >> 6) & M1), (int)((z[1] >> 6) & M1), (int)((z[2] >> 6) & M1), (int)((z[3] >> 6) & M1)};
+                    zcc0[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, z0, zcc0[t], 0, 0, 0);
+                    zcc1[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, z1, zcc1[t], 0, 0, 0);
+                    zcc2[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, z2, zcc2[t], 0, 0, 0);
+                    zcc0[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a3, z3, zcc0[t], 0, 0, 0);
                 }
                 const pg_v4i b0 = {(int)(y[0] & M0), (int)(y[1] & M0), (int)(y[2] & M0), (int)(y[3] & M0)};
                 const pg_v4i b1 = {(int)(y[0] & (M0 << 2)), (int)(y[1] & (M0 << 2)), (int)(y[2] & (M0 << 2)), (int)(y[3] & (M0 << 2))};
@@ -809,16 +840,23 @@ __global__ __launch_bounds__(256) void k_pg_mfma(const uint8_t* __restrict__ bed
             __syncthreads();
         }
     }
-    // C: column n = individual of the tile, rows 4 kg + r = planes.  kg = 0: the four digits of part 1, kg = 1: of part 2.
-    if (live && kg < 2) {
+    // C: column n = individual of the tile, rows 4 kg + r = planes.  kg = 0: the four digits of part 1 of C, kg = 1: of part 2;
+    // DIRTY: kg = 2, 3: the same of D, from the indicator set.
+    if (live && (DIRTY || kg < 2)) {
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             long long sx = 0;
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                sx += (long long)(acc0[t][r] + (acc1[t][r] >> 2) + (acc2[t][r] >> 4)) << (8 * r);
+            for (int r = 0; r < 4; r++) {
+                int v = acc0[t][r] + (acc1[t][r] >> 2) + (acc2[t][r] >> 4);
+                if constexpr (DIRTY) {
+                    const int vz = zcc0[t][r] + (zcc1[t][r] >> 2) + (zcc2[t][r] >> 4);
+                    v = kg < 2 ? v : vz;
+                }
+                sx += (long long)v << (8 * r);
+            }
             const size_t ind = 4 * ibyte + 16 * (size_t)t + (size_t)n;
-            if (sx != 0) atomicAdd(gacc + 2 * ind + kg, (unsigned long long)sx);
+            if (sx != 0) atomicAdd(gacc + 2 * ind + (kg & 1), (unsigned long long)sx);
         }
     }
 }
@@ -835,24 +873,25 @@ __global__ void k_pg_finish(const unsigned long long* __restrict__ gacc, const l
 }
 size_t predict_workspace_bytes(size_t stride, int M) {
     const size_t Mpad = ((size_t)(M > 0 ? M : 1) + PG_KB - 1) / PG_KB * PG_KB;
-    return 8 * Mpad + 16 * 4 * stride + 64;
+    return 16 * Mpad + 16 * 4 * stride + 64;
 }
-// ws: predict_workspace_bytes(stride, M) bytes.  Every marker of the block must be free of missing genotypes among the phenotyped
-// individuals (the caller checks the marker statistics' flags); g receives 4 * stride doubles.
+// ws: predict_workspace_bytes(stride, M) bytes.  dirty = 0 only if every marker of the block is free of missing genotypes among
+// the phenotyped individuals (the caller checks the marker statistics' flags); g receives 4 * stride doubles.
 hipError_t launch_predict_g_mfma(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* mave,
-                                 const double* msig, const double* beta, double* g, void* ws, hipStream_t st) {
+                                 const double* msig, const double* beta, double* g, void* ws, int dirty, hipStream_t st) {
     if (stride == 0 || M <= 0) return hipSuccess;
     const size_t Mpad = ((size_t)M + PG_KB - 1) / PG_KB * PG_KB;
     uint8_t* planes = static_cast<uint8_t*>(ws);
-    unsigned long long* gacc = reinterpret_cast<unsigned long long*>(planes + 8 * Mpad);
+    unsigned long long* gacc = reinterpret_cast<unsigned long long*>(planes + 16 * Mpad);
     unsigned long long* maxbits = gacc + 2 * 4 * stride;
     long long* dsum = reinterpret_cast<long long*>(maxbits + 2);
     hipError_t e = hipMemsetAsync(gacc, 0, 16 * 4 * stride + 64, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_pg_absmax, dim3(256), dim3(256), 0, st, mave, msig, beta, M, maxbits);
-    hipLaunchKernelGGL(k_pg_planes, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, st, mave, msig, beta, M, Mpad, maxbits, planes, dsum);
+    hipLaunchKernelGGL(k_pg_planes, dim3((unsigned)((Mpad + 255) / 256)), dim3(256), 0, st, mave, msig, beta, M, Mpad, maxbits, planes, dsum, dirty);
     const unsigned gx = (unsigned)((stride + 63) / 64 + 63) / 64 * 64, gy = (unsigned)(((size_t)M + (size_t)PG_STAGES * PG_KB - 1) / ((size_t)PG_STAGES * PG_KB));
-    hipLaunchKernelGGL(k_pg_mfma, dim3(gx, gy), dim3(256), 0, st, bed, stride, M, planes, Mpad, gacc);
+    if (dirty) hipLaunchKernelGGL(k_pg_mfma<true>, dim3(gx, gy), dim3(256), 0, st, bed, stride, M, planes, Mpad, gacc);
+    else hipLaunchKernelGGL(k_pg_mfma<false>, dim3(gx, gy), dim3(256), 0, st, bed, stride, M, planes, Mpad, gacc);
     hipLaunchKernelGGL(k_pg_finish, dim3((unsigned)((4 * stride + 255) / 256)), dim3(256), 0, st, gacc, dsum, namask2, 4 * stride, maxbits, g);
     return hipGetLastError();
 }
