@@ -159,6 +159,7 @@ static int ctx_create_body(gmrm_ctx* c, int device, int N, int M, int Mt, int S,
                                      " resident workgroups (occupancy query x compute units)");
     }
     if (const char* e = std::getenv("GMRM_NB_FACTOR16")) { int v = std::atoi(e); if (v >= 8 && v <= 256) c->nb_factor16 = v; }
+    if (const char* e = std::getenv("GMRM_PF_AHEAD16")) { int v = std::atoi(e); if (v >= 0 && v <= 16) c->pf_ahead16 = v; }
     if (const char* e = std::getenv("GMRM_SPEC_FACTOR16")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) c->spec_factor16 = v; }
     if (const char* e = std::getenv("GMRM_CROSS_FRAC16")) { int v = std::atoi(e); if (v >= 1 && v <= 16) c->cross_frac16 = v; }
     if (const char* e = std::getenv("GMRM_CROSS_DENSITY")) { double v = std::atof(e); if (v >= 0.0 && v <= 1.0) c->cross_density = v; }
@@ -669,6 +670,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     }
     a.nb_factor16 = c->nb_factor16;
     a.spec_factor16 = c->spec_factor16;
+    a.pf_ahead16 = c->pf_ahead16;
     a.miss_mode = tr.miss_mode;
     if (std::getenv("GMRM_FORCE_MIXED")) a.miss_mode = 1;     // diagnostic: run any block through the per-marker-layout kernel
     // The walk may cross markers whose effect was non-zero: when no marker of the block has a missing genotype among the

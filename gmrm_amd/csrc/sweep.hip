@@ -1847,7 +1847,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // request the slices / sampling inputs the ring can take once the current batch has been walked to its
         // end.  Wavefronts 1-3 get here at once (they skip the block above) and issue while wavefront 0 samples;
         // the column loads wait for the totals (gate inside).
-        prefetch_issue(pos + cur.nb + RPOS, cur.gen + 1u);
+        prefetch_issue(pos + ((cur.nb * a.pf_ahead16) >> 4) + RPOS, cur.gen + 1u);
         meta_issue(pos + cur.nb + META_POS);
         PROF(2);   // prefetch issue
         if (bad) ctl[C_BAD] = 1;
