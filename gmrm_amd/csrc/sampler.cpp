@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -394,11 +395,31 @@ int gmrm_sampler_end_sweep(gmrm_sampler* s, int* cass, double* beta_sqn) {
         }
         c.n_updates = out.n_updates; c.n_batches = out.n_batches; c.sweep_ms = out.device_ms;
         c.n_planned = out.n_planned_stops; c.n_stale = out.n_stale_dots; c.n_fastb = out.n_fast_batches; c.n_cross = out.n_crossed_stops;
+        static const bool prof = std::getenv("GMRM_HOST_PROF") != nullptr;
+        const auto ta = std::chrono::steady_clock::now();
         if (ctx->M > 0)
             if (int r = gmrm_get_betas(ctx, t, c.betas.data())) { rc = r; continue; }
+        const auto tb = std::chrono::steady_clock::now();
         std::fill(c.beta_sqn.begin(), c.beta_sqn.end(), 0.0);
-        for (int i = 0; i < ctx->M; i++)
-            c.beta_sqn[s->group_index[ctx->S + i]] += c.betas[i] * c.betas[i];
+        // (bayes.cpp:562-566 adds beta^2 of every marker in marker order; a zero effect adds +0.0, which leaves a sum of
+        // non-negative terms as it is -- skipping it is the same sum without a dependent f64 add per marker: 2.4 ms -> 0.3 ms
+        // per million markers, of which ~7 k are in the model)
+        const double* bp = c.betas.data();
+        const int* gp = s->group_index.data() + ctx->S;
+        const int M8 = ctx->M & ~7;
+        for (int i0 = 0; i0 < M8; i0 += 8) {                 // eight effects at a time: all zero (as bits, sign aside) in most places
+            uint64_t w[8];
+            std::memcpy(w, bp + i0, sizeof(w));
+            if (((w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) << 1) == 0) continue;
+            for (int i = i0; i < i0 + 8; i++)
+                if (bp[i] != 0.0) c.beta_sqn[gp[i]] += bp[i] * bp[i];
+        }
+        for (int i = M8; i < ctx->M; i++)
+            if (bp[i] != 0.0) c.beta_sqn[gp[i]] += bp[i] * bp[i];
+        if (prof)
+            std::fprintf(stderr, "[host prof end_sweep] effects to the host %.0f us, beta_sqn loop %.0f us\n",
+                         std::chrono::duration<double, std::micro>(tb - ta).count(),
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb).count());
         if (cass) std::memcpy(cass + (size_t)t * G * K, c.cass.data(), sizeof(int) * (size_t)G * K);
         if (beta_sqn) std::memcpy(beta_sqn + (size_t)t * G, c.beta_sqn.data(), sizeof(double) * (size_t)G);
     }
@@ -452,12 +473,28 @@ int gmrm_sampler_iterate(gmrm_sampler* s, int it) {
     if (s->nranks != 1) return fail(GMRM_ESTATE, "gmrm_sampler_iterate is the single-shard form; use the split calls");
     const int T = s->ctx->T;
     std::vector<double> mu(T);
+    static const bool prof = std::getenv("GMRM_HOST_PROF") != nullptr;     // where the host's share of an iteration goes (stderr)
+    const auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::micro>(b - a).count();
+    };
+    const auto t0 = now();
     if (int r = gmrm_sampler_draw_mu(s, it, mu.data())) return r;
-    if (int r = gmrm_sampler_begin_sweep(s, mu.data())) return r;
+    const auto t1 = now();
+    if (int r = gmrm_sampler_launch_sweep(s, mu.data())) return r;
+    const auto t2 = now();
+    if (int r = gmrm_sampler_preshuffle(s)) return r;
+    const auto t3 = now();
     std::vector<int> cass((size_t)T * s->G * s->K);
     std::vector<double> bsq((size_t)T * s->G);
     if (int r = gmrm_sampler_end_sweep(s, cass.data(), bsq.data())) return r;
-    return gmrm_sampler_epilogue(s, cass.data(), bsq.data());
+    const auto t4 = now();
+    const int rc = gmrm_sampler_epilogue(s, cass.data(), bsq.data());
+    if (prof)
+        std::fprintf(stderr, "[host prof it %d] draw_mu %.0f us, launch (offset, order upload, kernel launch) %.0f, next shuffle %.0f (beside the kernel), "
+                             "end_sweep %.0f (kernel %.0f ms inside), epilogue %.0f\n", it, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4),
+                     (double)s->ch[0].sweep_ms, us(t4, now()));
+    return rc;
 }
 
 int gmrm_sampler_get(gmrm_sampler* s, int t, gmrm_hyper* out) {
