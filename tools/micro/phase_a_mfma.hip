@@ -195,7 +195,161 @@ template <int V> static void run(const char* name, int nbv) {
     hipFree(dr); hipFree(d1); hipFree(d2); hipFree(dout); hipFree(dc);
 }
 
+// ---- V2: the same contraction on v_mfma_scale_f32_16x16x128_f8f6f4, operand A = FP4 (the ring's 2-bit code in the low half of
+// a nibble is the FP4 code of c'/2: one v_and per register), operand B = FP6 E3M2 balanced base-16 digits of the residual's
+// 53-bit grid integer (13 planes of 16 columns), K = 128 individuals per instruction.  Same work split and software pipeline
+// as V0, one tile per pass.  Digit planes in LDS: per plane and K-block of 128 individuals 4 x (16 + 8) bytes (a lane's 32
+// six-bit elements), the 16-byte and the 8-byte parts in two arrays so that both reads are aligned.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int NKB = 4 * SB / 128;                   // K-blocks per slice
+constexpr int P6A = NKB * 64 + 16, P6B = NKB * 32 + 8;   // plane strides of the two arrays (+ pad: the 16 planes hit different banks)
+__host__ __device__ inline uint32_t e3m2(int d) {
+    const uint32_t sg = d < 0 ? 32u : 0u;
+    const int a = d < 0 ? -d : d;
+    const uint8_t code[9] = {0, (3 << 2) | 0, (4 << 2) | 0, (4 << 2) | 2, (5 << 2) | 0, (5 << 2) | 1, (5 << 2) | 2, (5 << 2) | 3, (6 << 2) | 0};
+    return sg | code[a];
+}
+__global__ __launch_bounds__(256, 1) void k2(const uint8_t* ringsrc, const long long* esrc, long long* out, long long* cyc, int iters, int nb) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint8_t* ring = smem;
+    uint32_t* pa = reinterpret_cast<uint32_t*>(smem + RING * SB);                   // 16 planes x P6A bytes
+    uint32_t* pb = reinterpret_cast<uint32_t*>(smem + RING * SB + 16 * P6A);        // 16 planes x P6B bytes
+    unsigned long long* sall = reinterpret_cast<unsigned long long*>(smem + RING * SB + 16 * P6A + 16 * P6B);   // 128 * 2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < RING * SB / 16; i += 256) {
+        const int pos = i / CPP, c = i % CPP;
+        uint4 v = reinterpret_cast<const uint4*>(ringsrc)[i];
+        v.x = recode(v.x); v.y = recode(v.y); v.z = recode(v.z); v.w = recode(v.w);
+        reinterpret_cast<uint4*>(ring)[pos * CPP + (c ^ (pos & (CPP - 1)))] = v;
+    }
+    for (int i = tid; i < (16 * P6A + 16 * P6B) / 4; i += 256) pa[i] = 0;
+    sall[tid] = 0;
+    __syncthreads();
+    for (int ind = tid; ind < 4 * SB; ind += 256) {
+        long long e = esrc[ind];
+        const int kb = ind >> 7, w = ind & 127, kg = w >> 5, w32 = w & 31, q = w32 >> 4, f = w32 & 15, h = f & 1, el = f >> 1;
+        const int j = 8 * (2 * q + h) + el;                       // element of the lane's 32 (operand order, mfma_fp4_fp6.hip)
+        for (int pl = 0; pl < 13; pl++) {
+            const int d = (int)(((e + 8) & 15) - 8);
+            e = (e - d) >> 4;
+            const unsigned long long c = e3m2(pl == 12 ? (int)(e * 16 + d) : d);      // the top digit takes what is left (|.| <= 8)
+            const int bit = 6 * j;                                    // within the 192-bit fragment: bits 0..127 -> array A, 128..191 -> array B
+            for (int k = 0; k < 6; k++) {
+                if (!((c >> k) & 1)) continue;
+                const int bb = bit + k;
+                if (bb < 128) atomicOr(&pa[(pl * P6A + kb * 64 + kg * 16) / 4 + (bb >> 5)], 1u << (bb & 31));
+                else atomicOr(&pb[(pl * P6B + kb * 32 + kg * 8) / 4 + ((bb - 128) >> 5)], 1u << (bb & 31));
+            }
+        }
+    }
+    __syncthreads();
+    const int nt = (nb + 15) / 16;
+    const int tsplit = nt >= 4 ? 4 : (nt >= 2 ? 2 : 1), ksplit = 4 / tsplit;
+    const int wt = wave % tsplit, wk = wave / tsplit;
+    const int nkb = NKB / ksplit, kb0 = wk * nkb;
+    const int mrow = lane & 15, kg = lane >> 4;
+    long long t0 = clock64(); const long long w0 = wall_clock64();
+    long long sink = 0;
+    for (int it = 0; it < iters; it++) {
+        const int pbase = (it * 7) % RING;
+        for (int t = wt; t < nt; t += tsplit) {
+            const int mk = 16 * t + mrow;
+            const int pos = (pbase + (mk < nb ? mk : nb - 1)) % RING;
+            const uint8_t* slice = ring + pos * SB;
+            const int swz = pos & (CPP - 1);
+            v4f acc = {0.f, 0.f, 0.f, 0.f};
+            auto load_w = [&](int s) {                                // 8 bytes: the lane's 32 individuals of K-block kb0 + s
+                const int kb = kb0 + (s < nkb ? s : nkb - 1);
+                const int byte = 32 * kb + 8 * kg;                    // chunk byte / 16, swizzled per chunk
+                return *reinterpret_cast<const uint2*>(slice + 16 * ((byte >> 4) ^ swz) + (byte & 15));
+            };
+            struct BB { uint4 lo; uint2 hi; };
+            auto load_b = [&](int s) {
+                const int kb = kb0 + (s < nkb ? s : nkb - 1);
+                BB r;
+                r.lo = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(pa) + mrow * P6A + kb * 64 + kg * 16);
+                r.hi = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(pb) + mrow * P6B + kb * 32 + kg * 8);
+                return r;
+            };
+            uint2 w = load_w(0);
+            BB bb = load_b(0);
+#pragma unroll 2
+            for (int s = 0; s < nkb; s++) {
+                const uint2 wn = load_w(s + 1);
+                const BB bn = load_b(s + 1);
+                const v8i a = {(int)(w.x & 0x33333333u), (int)((w.x >> 2) & 0x33333333u), (int)(w.y & 0x33333333u), (int)((w.y >> 2) & 0x33333333u), 0, 0, 0, 0};
+                const v8i b = {(int)bb.lo.x, (int)bb.lo.y, (int)bb.lo.z, (int)bb.lo.w, (int)bb.hi.x, (int)bb.hi.y, 0, 0};
+                acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, acc, 4, 3, 0, 127, 0, 127);
+                w = wn; bb = bn;
+            }
+            // C: column n = lane & 15 (plane), rows 4 kg + r (marker).  T_n = 2 acc is an integer below 2^16 per workgroup slice:
+            // four planes combine in an int32 (quad), two quads in an int64; planes 0-7 and 8-12 are the two exchanged parts
+            const int n = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int v = (int)(acc[r] * 2.0f) << (4 * (n & 3));
+                v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+                v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+                const int up = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0xf, false);     // row_shl:4: the next quad's sum
+                const long long y = (long long)v + ((long long)up << 16);
+                const int m = 16 * t + 4 * kg + r;
+                if ((n & 7) == 0 && m < nb) atomicAdd(&sall[m * 2 + (n >> 3)], (unsigned long long)y);
+            }
+        }
+        __syncthreads();
+        if (it == 0 && tid < nb * 2) out[(size_t)blockIdx.x * 256 + tid] = (long long)sall[tid];
+        if (tid < nb * 2) { sink += (long long)sall[tid]; sall[tid] = 0; }
+        __syncthreads();
+    }
+    const long long t1 = clock64();
+    if (tid == 0) { cyc[blockIdx.x] = t1 - t0; cyc[gridDim.x + blockIdx.x] = wall_clock64() - w0; if (sink == 0x1234567) out[0] = sink; }
+}
+static void run2(int nbv) {
+    const int blocks = 245, iters = 200;
+    std::vector<uint8_t> ring((size_t)RING * SB);
+    std::vector<long long> e(SB * 4);
+    srand(7);
+    for (auto& b : ring) b = (uint8_t)(rand() & 0xff);
+    for (auto& x : e) x = (long long)(((((unsigned long long)rand() << 40) ^ ((unsigned long long)rand() << 20) ^ (unsigned long long)rand()) % (1ull << 51))) * ((rand() & 1) ? 1 : -1);
+    for (int m = 0; m < RING; m++)
+        for (int g = 0; g < SB; g++)
+            for (int j = 0; j < 4; j++)
+                if (((ring[(size_t)m * SB + g] >> (2 * j)) & 3) == 1) ring[(size_t)m * SB + g] ^= (uint8_t)(2u << (2 * j));   // 01 -> 11
+    uint8_t* dr; long long *de, *dout, *dc;
+    hipMalloc(&dr, ring.size()); hipMalloc(&de, e.size() * 8);
+    hipMalloc(&dout, (size_t)blocks * 256 * 8); hipMalloc(&dc, blocks * 16);
+    hipMemcpy(dr, ring.data(), ring.size(), hipMemcpyHostToDevice);
+    hipMemcpy(de, e.data(), e.size() * 8, hipMemcpyHostToDevice);
+    const size_t sm = (size_t)RING * SB + 16 * P6A + 16 * P6B + 256 * 8;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(k2, dim3(blocks), dim3(256), sm, 0, dr, de, dout, dc, iters, nbv);
+    hipLaunchKernelGGL(k2, dim3(blocks), dim3(256), sm, 0, dr, de, dout, dc, iters, nbv);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("fp4 x fp6: launch failed (%zu bytes of LDS)\n", sm); return; }
+    std::vector<long long> out((size_t)blocks * 256), cyc(blocks * 2);
+    hipMemcpy(out.data(), dout, out.size() * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(cyc.data(), dc, cyc.size() * 8, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int m = 0; m < nbv; m++) {
+        __int128 s = 0;
+        for (int g = 0; g < SB; g++) {
+            const uint8_t b = ring[(size_t)m * SB + g];
+            for (int j = 0; j < 4; j++) {
+                const int c = (b >> (2 * j)) & 3; const int a = c == 0 ? 2 : (c == 2 ? 1 : 0);
+                s += (__int128)a * e[g * 4 + j];
+            }
+        }
+        // out: low = sum over planes 0-7 (units 1), high = planes 8-12 (units 2^32)
+        const __int128 got = (__int128)out[m * 2] + ((__int128)out[m * 2 + 1] << 32);
+        if (got != s) bad++;
+    }
+    double avg = 0, wl = 0; for (int i = 0; i < blocks; i++) { avg += (double)cyc[i]; wl += (double)cyc[blocks + i]; } avg /= blocks; wl /= blocks;
+    printf("%-28s markers %3d: %8.0f clk/batch  %6.1f clk/marker  %6.2f us/batch (%s)\n", "mfma fp4 x fp6, K = 128", nbv, avg / iters, avg / iters / nbv, wl / iters * 0.01, bad ? "MISMATCH" : "exact");
+    hipFree(dr); hipFree(de); hipFree(dout); hipFree(dc);
+}
+
 int main() {
+    for (int nb : {128, 120, 64, 32, 16}) run2(nb);
     for (int nb : {128, 120, 64, 32, 16}) run<0>("mfma i8, recoded fields", nb);
     for (int nb : {128, 64, 16}) run<1>("mfma i8, byte table in LDS", nb);
     return 0;
