@@ -1552,6 +1552,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     }
                 }
             }
+#ifdef GM_PA_SPLIT
+            PA(1);   // (diagnostic: "scan + inputs" then also holds the MFMA loop, "tiles" only the tile output)
+#endif
             // C: column n = lane & 15 (digit plane), rows 4 kg + r (marker of the tile).  The four planes of
             // one exact part meet in a quad: sum_p digit_p * 256^p as a 64-bit integer; the parts of the slice
             // (ksplit wavefronts) meet in LDS (integer: exact, any order).
