@@ -241,7 +241,6 @@ int gmrm_sampler_abort_steps(gmrm_sampler* s) {
 
 int gmrm_sampler_begin_steps(gmrm_sampler* s, const double* mu_use) {
     if (!s || !mu_use) return fail(GMRM_EINVAL, "null argument");
-    gmrm_ctx* ctx = s->ctx;
     if (const char* why = busy_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_begin_steps: ") + why);
     const int rc = begin_steps_body(s, mu_use);
     if (rc != GMRM_OK) {                                          // phenotypes already switched over go back
