@@ -24,7 +24,7 @@ GMAX = 64
 class SweepIn(C.Structure):
     _fields_ = [("G", C.c_int), ("K", C.c_int), ("order", c_int_p), ("sigmag", c_double_p),
                 ("pi_est", c_double_p), ("cva", c_double_p), ("sigmae", C.c_double),
-                ("rng_state", C.c_uint32 * 624), ("rng_index", C.c_int)]
+                ("rng_state", C.c_uint32 * 624), ("rng_index", C.c_int), ("first", C.c_int), ("count", C.c_int)]
 
 
 class SweepOut(C.Structure):
@@ -116,6 +116,9 @@ SIGNATURES = {
     "gmrm_sampler_begin_sweep": (C.c_int, [VP, c_double_p]),
     "gmrm_sampler_launch_sweep": (C.c_int, [VP, c_double_p]),
     "gmrm_sampler_preshuffle": (C.c_int, [VP]),
+    "gmrm_sampler_begin_parts": (C.c_int, [VP, c_double_p]),
+    "gmrm_sampler_launch_part": (C.c_int, [VP, C.c_int, C.c_int]),
+    "gmrm_sampler_finish_part": (C.c_int, [VP]),
     "gmrm_sampler_end_sweep": (C.c_int, [VP, c_int_p, c_double_p]),
     "gmrm_sampler_epilogue": (C.c_int, [VP, c_int_p, c_double_p]),
     "gmrm_sampler_begin_steps": (C.c_int, [VP, c_double_p]),

@@ -316,6 +316,33 @@ class Sampler:
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         check(self.lib.gmrm_sampler_begin_sweep(self.h, _dp(mu)))
 
+    # a sweep in parts (--sync-every k: marker shards exchange their residuals every k markers; include/gmrm_hip.h)
+    def begin_parts(self, mu):
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        check(self.lib.gmrm_sampler_begin_parts(self.h, _dp(mu)))
+
+    def launch_part(self, first, count):
+        check(self.lib.gmrm_sampler_launch_part(self.h, int(first), int(count)))
+
+    def finish_part(self):
+        check(self.lib.gmrm_sampler_finish_part(self.h))
+
+    def iterate_parts(self, it, k):
+        """One iteration of a single shard with the sweep cut into parts of k markers: the same chain as iterate()."""
+        mu = self.draw_mu(it)
+        self.begin_parts(mu)
+        M = self.ctx.M
+        first = 0
+        while True:
+            n = min(int(k), M - first)
+            self.launch_part(first, n)
+            self.finish_part()
+            first += n
+            if first >= M:
+                break
+        cass, bsq = self.end_sweep()
+        self.epilogue(cass, bsq)
+
     def end_sweep(self):
         T = self.ctx.T
         cass = np.zeros((T, self.G, self.K), dtype=np.int32)

@@ -607,10 +607,18 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     if (G < 1 || G > GMAX || K < 2 || K > KMAX) return fail(GMRM_EINVAL, "G or K outside the supported range (G<=64, 2<=K<=8)");
     if (in->rng_index < 0 || in->rng_index > 624) return fail(GMRM_EINVAL, "rng_index out of range");
     if (!(in->sigmae > 0.0)) return fail(GMRM_EINVAL, "sigmae must be positive");
+    // a part of the sweep: positions [first, first + count) of the order (count == 0: all of it)
+    const int first = in->count == 0 ? 0 : in->first, count = in->count == 0 ? c->M : in->count;
+    if (in->count != 0 && (in->first < 0 || in->count < 0 || (long long)in->first + in->count > c->M))
+        return fail(GMRM_EINVAL, "part of the sweep outside [0, M)");
+    if (first != tr.part_next && !(first == 0))
+        return fail(GMRM_ESTATE, "parts of a sweep must be launched in order of position (expected first = " + std::to_string(tr.part_next) + ")");
     HIPCHK(hipSetDevice(c->device));
     tr.G = G; tr.K = K;
     if (c->M == 0) { tr.in_flight = true; tr.empty = true; return GMRM_OK; }
     tr.empty = false;
+    tr.part_last = first + count == c->M;
+    tr.part_next = tr.part_last ? 0 : first + count;
 
     // per-group tables of the Gibbs step, evaluated exactly as bayes.cpp:403-432 writes them
     std::vector<double> tab((size_t)G * (1 + 3 * K), 0.0);
@@ -635,7 +643,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     }
     // blocking copies: the sources (a local table, the caller's sweep_in) need not outlive this call
     HIPCHK(hipMemcpy(tr.tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(tr.order, in->order, (size_t)c->M * sizeof(int), hipMemcpyHostToDevice));
+    if (first == 0) HIPCHK(hipMemcpy(tr.order, in->order, (size_t)c->M * sizeof(int), hipMemcpyHostToDevice));   // (later parts: the same order)
     HIPCHK(hipMemcpy(tr.rng_state, in->rng_state, 624 * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(tr.rng_index, &in->rng_index, sizeof(int), hipMemcpyHostToDevice));
     // every polled word starts at zero in every launch (tags count from 1 inside the launch)
@@ -643,13 +651,13 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     HIPCHK(hipMemsetAsync(tr.P, 0, (size_t)4 * SW_VMAX * c->Wpad * sizeof(double), tr.stream));
     HIPCHK(hipMemsetAsync(tr.Tt, 0, (size_t)4 * SW_VMAX * sizeof(double), tr.stream));
     HIPCHK(hipMemsetAsync(tr.err, 0, 4 * sizeof(int), tr.stream));
-    HIPCHK(hipMemsetAsync(tr.cass, 0, (size_t)GMAX * KMAX * sizeof(int), tr.stream));   // every workgroup adds its share
+    if (first == 0) HIPCHK(hipMemsetAsync(tr.cass, 0, (size_t)GMAX * KMAX * sizeof(int), tr.stream));   // every workgroup adds its share; the parts of a sweep add up
     HIPCHK(hipMemsetAsync(tr.stats, 0, 40 * sizeof(long long), tr.stream));
 
     SweepArgs a{};
-    a.N = c->N; a.M = c->M; a.W = c->W; a.Wpad = c->Wpad; a.G = G; a.K = K;
+    a.N = c->N; a.M = count; a.W = c->W; a.Wpad = c->Wpad; a.G = G; a.K = K;
     a.stride = c->stride;
-    a.bed = c->bed; a.namask2 = tr.namask2; a.order = tr.order; a.group = c->group;
+    a.bed = c->bed; a.namask2 = tr.namask2; a.order = tr.order + first; a.group = c->group;
     a.mave = tr.mave; a.msig = tr.msig; a.nomiss = tr.nomiss;
     a.betas_in = tr.betas[tr.cur]; a.betas_out = tr.betas[tr.cur ^ 1];
     a.comp = tr.comp; a.acum = tr.acum; a.eps = tr.eps;
@@ -683,7 +691,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     // is the same either way, bit for bit.  GMRM_NO_CROSS=1 / GMRM_FORCE_CROSS=1: A/B knobs.
     a.cross = 0;
     if ((a.miss_mode == 0 || a.miss_mode == 2) && !std::getenv("GMRM_NO_CROSS")) {      // (the mixed layout, mode 1, has no such kernel)
-        const bool dense = (double)tr.in_model >= c->cross_density * (double)c->M;
+        const bool dense = (double)tr.in_model >= c->cross_density * (double)c->M;      // (as of the last completed sweep)
         if (dense || std::getenv("GMRM_FORCE_CROSS")) a.cross = c->cross_frac16;
     }
     a.spin_ticks = (unsigned long long)c->spin_timeout_ms * 100000ull;      // s_memrealtime ticks (100 MHz)
@@ -757,13 +765,16 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
         if (err[0] == 4) return fail(GMRM_EKERNEL, "sweep kernel: |residual| reached 2^8 inside the sweep: outside the range of the exact-summation bins");
         return fail(GMRM_EKERNEL, "sweep kernel: unknown error code " + std::to_string(err[0]));
     }
-    tr.cur ^= 1;
-    // component counts of this sweep; markers in the model afterwards = those not in component 0 (the next launch's choice of kernel)
+    if (tr.part_last) tr.cur ^= 1;                  // (a part that does not end the sweep: the old effects stay current)
+    // component counts of this sweep (so far, if it runs in parts); markers in the model afterwards = those not in
+    // component 0 (the next launch's choice of kernel)
     std::vector<int> hc((size_t)tr.G * tr.K);
     HIPCHK(hipMemcpy(hc.data(), tr.cass, sizeof(int) * hc.size(), hipMemcpyDeviceToHost));
-    tr.in_model = 0;
-    for (int g = 0; g < tr.G; g++)
-        for (int k = 1; k < tr.K; k++) tr.in_model += hc[(size_t)g * tr.K + k];
+    if (tr.part_last) {
+        tr.in_model = 0;
+        for (int g = 0; g < tr.G; g++)
+            for (int k = 1; k < tr.K; k++) tr.in_model += hc[(size_t)g * tr.K + k];
+    }
     if (out) {
         long long st[40];
         HIPCHK(hipMemcpy(st, tr.stats, sizeof(st), hipMemcpyDeviceToHost));

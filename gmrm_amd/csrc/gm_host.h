@@ -23,6 +23,8 @@ struct Trait {
     double* acum = nullptr;         // Phenotype::acum [M]
     int nonas = 0;
     bool have_trait = false, have_stats = false, in_flight = false, empty = false;
+    int part_next = 0;              // a sweep in parts (gmrm_sweep_in.first / count): the position the next part starts at (0: a new sweep)
+    bool part_last = true;          // the part in flight ends the sweep: its finish makes the new effects current
     bool holds_devlock = false;     // this sweep holds the per-device advisory lock against other processes (capi.cpp)
     bool poisoned = false;          // a sweep failed inside the kernel: comp / acum partly written, sweeps refused until re-upload
     long long in_model = 0;         // markers with a non-zero effect (betas[cur]): from the last sweep's component counts / gmrm_set_betas

@@ -155,11 +155,11 @@ int gmrm_sampler_draw_mu(gmrm_sampler* s, int it, double* mu_drawn) {
     return GMRM_OK;
 }
 
-// bayes.cpp:358-367 with the adopted mu, then the marker loop is launched (asynchronous); nothing else
-int gmrm_sampler_launch_sweep(gmrm_sampler* s, const double* mu_use) {
+// bayes.cpp:358-367 with the adopted mu: the residual loses mu, the markers are shuffled, the counts start at zero; no launch
+int gmrm_sampler_begin_parts(gmrm_sampler* s, const double* mu_use) {
     if (!s || !mu_use) return fail(GMRM_EINVAL, "null argument");
     gmrm_ctx* ctx = s->ctx;
-    if (const char* why = busy_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_launch_sweep: ") + why);
+    if (const char* why = busy_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_begin_parts: ") + why);
     for (int t = 0; t < ctx->T; t++) {
         Chain& c = s->ch[t];
         c.mu = mu_use[t];
@@ -168,9 +168,22 @@ int gmrm_sampler_launch_sweep(gmrm_sampler* s, const double* mu_use) {
         c.preshuffled = false;
         std::fill(c.m0.begin(), c.m0.end(), 0);
         std::fill(c.cass.begin(), c.cass.end(), 0);
-        if (s->nranks > 1)
-            if (int r = gmrm_eps_snapshot(ctx, t)) return r;
+        c.n_updates = 0; c.n_batches = 0; c.sweep_ms = 0.0; c.n_planned = 0; c.n_stale = 0; c.n_fastb = 0; c.n_cross = 0;
     }
+    return GMRM_OK;
+}
+
+// The marker loop over positions [first, first + count) of the visit order is launched (asynchronous).  With several
+// shards the residual is remembered first: what this part adds to it is what the shards exchange behind it.
+int gmrm_sampler_launch_part(gmrm_sampler* s, int first, int count) {
+    if (!s) return fail(GMRM_EINVAL, "null sampler");
+    gmrm_ctx* ctx = s->ctx;
+    if (first < 0 || count < 0 || (long long)first + count > ctx->M) return fail(GMRM_EINVAL, "part of the sweep outside [0, M)");
+    if (const char* why = busy_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_launch_part: ") + why);
+    if (s->nranks > 1)
+        for (int t = 0; t < ctx->T; t++)
+            if (int r = gmrm_eps_snapshot(ctx, t)) return r;
+    if (count == 0 && ctx->M > 0) return GMRM_OK;                // (a shard whose block is shorter than the others': nothing to do in this part)
     for (int t = 0; t < ctx->T; t++) {
         Chain& c = s->ch[t];
         gmrm_sweep_in in{};
@@ -182,9 +195,43 @@ int gmrm_sampler_launch_sweep(gmrm_sampler* s, const double* mu_use) {
         in.sigmae = c.sigmae;
         std::memcpy(in.rng_state, c.dist_d.mt, sizeof(in.rng_state));
         in.rng_index = c.dist_d.idx;
+        in.first = first; in.count = count;
         if (int r = gmrm_sweep_launch(ctx, t, &in)) return r;
     }
     return GMRM_OK;
+}
+
+// waits for the part in flight: the RNG stream and the counters move on, the component counts are the sweep's so far
+static int finish_one(gmrm_sampler* s, int t) {
+    gmrm_ctx* ctx = s->ctx;
+    Chain& c = s->ch[t];
+    gmrm_sweep_out out{};
+    out.cass = c.cass.data();
+    std::memcpy(out.rng_state, c.dist_d.mt, sizeof(out.rng_state));   // kept if M == 0
+    out.rng_index = c.dist_d.idx;
+    const bool empty = ctx->M == 0;
+    if (int r = gmrm_sweep_finish(ctx, t, &out)) return r;
+    if (!empty) {
+        std::memcpy(c.dist_d.mt, out.rng_state, sizeof(out.rng_state));
+        c.dist_d.idx = out.rng_index;
+    }
+    c.n_updates += out.n_updates; c.n_batches += out.n_batches; c.sweep_ms += out.device_ms;
+    c.n_planned += out.n_planned_stops; c.n_stale += out.n_stale_dots; c.n_fastb += out.n_fast_batches; c.n_cross += out.n_crossed_stops;
+    return GMRM_OK;
+}
+int gmrm_sampler_finish_part(gmrm_sampler* s) {
+    if (!s) return fail(GMRM_EINVAL, "null sampler");
+    int rc = GMRM_OK;
+    for (int t = 0; t < s->ctx->T; t++)
+        if (s->ctx->tr[t].in_flight)
+            if (int r = finish_one(s, t)) rc = r;
+    return rc;
+}
+
+// bayes.cpp:358-367 with the adopted mu, then the marker loop is launched (asynchronous); nothing else
+int gmrm_sampler_launch_sweep(gmrm_sampler* s, const double* mu_use) {
+    if (int r = gmrm_sampler_begin_parts(s, mu_use)) return r;
+    return gmrm_sampler_launch_part(s, 0, s->ctx->M);
 }
 
 // The marker loops are running on the GPU (the order was copied at launch).  The next iteration's
@@ -382,18 +429,8 @@ int gmrm_sampler_end_sweep(gmrm_sampler* s, int* cass, double* beta_sqn) {
     int rc = GMRM_OK;
     for (int t = 0; t < ctx->T; t++) {
         Chain& c = s->ch[t];
-        gmrm_sweep_out out{};
-        out.cass = c.cass.data();
-        std::memcpy(out.rng_state, c.dist_d.mt, sizeof(out.rng_state));   // kept if M == 0
-        out.rng_index = c.dist_d.idx;
-        const bool empty = ctx->M == 0;
-        if (int r = gmrm_sweep_finish(ctx, t, &out)) { rc = r; continue; }
-        if (!empty) {
-            std::memcpy(c.dist_d.mt, out.rng_state, sizeof(out.rng_state));
-            c.dist_d.idx = out.rng_index;
-        }
-        c.n_updates = out.n_updates; c.n_batches = out.n_batches; c.sweep_ms = out.device_ms;
-        c.n_planned = out.n_planned_stops; c.n_stale = out.n_stale_dots; c.n_fastb = out.n_fast_batches; c.n_cross = out.n_crossed_stops;
+        if (ctx->tr[t].in_flight)                       // (a sweep in parts has finished its last part already)
+            if (int r = finish_one(s, t)) { rc = r; continue; }
         static const bool prof = std::getenv("GMRM_HOST_PROF") != nullptr;
         const auto ta = std::chrono::steady_clock::now();
         if (ctx->M > 0)

@@ -153,6 +153,11 @@ typedef struct gmrm_sweep_in {
     double        sigmae;
     uint32_t      rng_state[624];   /* Distributions dist_d: mt19937 state words ...          */
     int           rng_index;        /* ... and position, 0..624                               */
+    /* A PART of a sweep (this build only: --sync-every k, residual exchange every k markers): positions [first, first +
+     * count) of `order`; count == 0 means the whole order.  The parts of one sweep are launched in order of position
+     * with the same `order`, each continuing the RNG stream the previous one returned; the component counts
+     * accumulate on the device over the parts, and the new effects become current with the part that ends at M. */
+    int           first, count;
 } gmrm_sweep_in;
 
 typedef struct gmrm_sweep_out {
@@ -244,6 +249,16 @@ int gmrm_sampler_begin_sweep(gmrm_sampler* s, const double* mu_use /*[T]*/);  /*
  * that drives several shards launches all of them before it shuffles for any (gmrm_group_iterate does). */
 int gmrm_sampler_launch_sweep(gmrm_sampler* s, const double* mu_use /*[T]*/);
 int gmrm_sampler_preshuffle(gmrm_sampler* s);
+/* A sweep in PARTS (this build only; `--sync-every k`, 1 < k < M: marker shards exchange their residuals every k markers
+ * instead of once per sweep -- closer to the reference's exchange after every marker, bayes.cpp:495-553, at k launches per
+ * sweep): gmrm_sampler_begin_parts = bayes.cpp:358-367 with the adopted mu, no launch; then, in order of position,
+ * gmrm_sampler_launch_part(first, count) (asynchronous; with several shards the residual is remembered first, as
+ * gmrm_eps_snapshot) and gmrm_sampler_finish_part (waits) -- the caller exchanges the residual deltas of the shards between
+ * a finish and the next launch (gmrm_eps_delta_export / _import) --, then gmrm_sampler_end_sweep and _epilogue as usual.
+ * One part [0, M) is gmrm_sampler_launch_sweep; on one shard any partition gives the same chain, bit for bit. */
+int gmrm_sampler_begin_parts(gmrm_sampler* s, const double* mu_use /*[T]*/);
+int gmrm_sampler_launch_part(gmrm_sampler* s, int first, int count);
+int gmrm_sampler_finish_part(gmrm_sampler* s);
 int gmrm_sampler_end_sweep(gmrm_sampler* s, int* cass /*[T*G*K]*/, double* beta_sqn /*[T*G]*/);
 int gmrm_sampler_epilogue(gmrm_sampler* s, const int* cass, const double* beta_sqn);
 int gmrm_sampler_adopt(gmrm_sampler* s, int t, const double* sigmag, const double* pi_est, double sigmae);

@@ -118,8 +118,9 @@ def run_oracle(case: Case, inp, iters=None, canon=True, nranks=1, seed=None, shu
     return hist
 
 
-def run_gpu(case: Case, inp, iters=None, seed=None, shuffle=True, mimic_hydra=False, device=0):
-    """The same history from the HIP path (single shard), through the C ABI."""
+def run_gpu(case: Case, inp, iters=None, seed=None, shuffle=True, mimic_hydra=False, device=0, parts=0):
+    """The same history from the HIP path (single shard), through the C ABI.  parts = k: every sweep cut into parts of k
+    markers (gmrm_sampler_launch_part: the same chain)."""
     import gmrm_amd
     iters = case.iters if iters is None else iters
     seed = case.seed if seed is None else seed
@@ -133,7 +134,10 @@ def run_gpu(case: Case, inp, iters=None, seed=None, shuffle=True, mimic_hydra=Fa
     hist = [dict(comp=[], betas=[], sigmae=[], sigmag=[], pi=[], mu=[], m0=[], csv=[], eps=None, nupd=[], nbatch=[], ncross=[])
             for _ in traits]
     for it in range(1, iters + 1):
-        smp.iterate(it)
+        if parts:
+            smp.iterate_parts(it, parts)
+        else:
+            smp.iterate(it)
         for t in range(len(traits)):
             hy = smp.hyper(t)
             h = hist[t]

@@ -33,6 +33,23 @@ def test_chain_matches_oracle_and_golden(gpu, name):
         assert sum(h["ncross"]) > 0 and h["nbatch"][-1] < h["nupd"][-1], (h["ncross"], h["nbatch"], h["nupd"])
 
 
+@pytest.mark.parametrize("name,k", [("small", 1), ("small", 37), ("ragged", 64), ("groups", 200), ("groups", 512)])
+def test_sweep_in_parts_is_the_same_chain(gpu, name, k):
+    """gmrm_sampler_begin_parts / _launch_part / _finish_part (the building block of `--sync-every k`): one shard that cuts
+    every sweep into parts of k markers -- down to one marker per launch, and one part that is the whole sweep -- walks the
+    chain of the ordinary sweep bit for bit (effects, components, residual, hyper-parameters, .csv bytes): the kernel takes a
+    range of the visit order, the RNG stream continues from part to part, the component counts add up on the device and
+    the new effects become current with the part that ends at M."""
+    case = cases.CASE_BY_NAME[name]
+    inp = cases.make_inputs(case)
+    got = cases.run_gpu(case, inp, iters=3, parts=k)
+    want = cases.run_oracle(case, inp, iters=3, canon=True)
+    cases.assert_same_history(got, want, exact=True)
+    whole = cases.run_gpu(case, inp, iters=3)
+    for hg, hw in zip(got, whole):
+        assert np.array_equal(hg["eps"], hw["eps"]) and hg["nupd"] == hw["nupd"]
+
+
 @pytest.mark.parametrize("kw", [dict(shuffle=False), dict(mimic_hydra=True), dict(seed=0)])
 def test_option_variants(gpu, kw):
     """--shuffle-markers 0, --mimic-hydra, --seed 0 (options.cpp:68-88, bayes.cpp:796-803)."""
