@@ -74,6 +74,7 @@ SIGNATURES = {
     "gmrm_group_uses_rccl": (C.c_int, [VP]),
     "gmrm_group_iterate": (C.c_int, [VP, C.c_int]),
     "gmrm_group_iterate_steps": (C.c_int, [VP, C.c_int]),
+    "gmrm_group_iterate_parts": (C.c_int, [VP, C.c_int, C.c_int]),
     "gmrm_group_destroy": (C.c_int, [VP]),
     "gmrm_rccl_selftest": (C.c_int, [C.c_int]),
     "gmrm_predict_g": (C.c_int, [VP, C.c_int, c_double_p, c_double_p]),

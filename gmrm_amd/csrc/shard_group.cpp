@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -219,6 +220,60 @@ extern "C" int gmrm_group_iterate(gmrm_group* g, int it) {
         if (int rc = gmrm_sampler_get(g->smp[0], t, &h)) return rc;
         for (int r = 1; r < n; r++)
             if (int rc = gmrm_sampler_adopt(g->smp[r], t, h.sigmag, h.pi_est, h.sigmae)) return rc;
+    }
+    return GMRM_OK;
+}
+
+// gmrm_group_iterate with the residual exchange every k marker positions instead of once per sweep (`--sync-every k`,
+// 1 < k < M; oracle: orc_nk_iterate): part p = positions [p k, (p + 1) k) of every shard's own visit order, all shards'
+// parts in flight together, the replicas reconciled behind every part (the same exact all-reduce of the deltas).
+extern "C" int gmrm_group_iterate_parts(gmrm_group* g, int it, int k) {
+    if (!g) return fail(GMRM_EINVAL, "null group");
+    if (k < 1) return fail(GMRM_EINVAL, "gmrm_group_iterate_parts: k must be positive");
+    const int n = g->n, T = g->T, G = g->G, K = g->K;
+    std::vector<double> mu0(T), mu(T);
+    for (int r = 0; r < n; r++)
+        if (int rc = gmrm_sampler_draw_mu(g->smp[r], it, r == 0 ? mu0.data() : mu.data())) return rc;
+    int Mm = 0;
+    for (int r = 0; r < n; r++) {
+        if (int rc = gmrm_sampler_begin_parts(g->smp[r], mu0.data())) return rc;
+        Mm = std::max(Mm, g->ctx[r]->M);
+    }
+    int rc = GMRM_OK;
+    for (int first = 0; first < Mm && rc == GMRM_OK; first += k) {
+        for (int r = 0; r < n && rc == GMRM_OK; r++) {
+            const int Mr = g->ctx[r]->M, f = std::min(first, Mr);
+            rc = gmrm_sampler_launch_part(g->smp[r], f, std::min(k, Mr - f));           // launches; returns at once
+        }
+        std::string keep = rc != GMRM_OK ? gmrm_last_error() : "";
+        for (int r = 0; r < n; r++) {                                                   // always: what is in flight must be collected
+            const int rc2 = gmrm_sampler_finish_part(g->smp[r]);
+            if (rc == GMRM_OK && rc2 != GMRM_OK) { rc = rc2; keep = gmrm_last_error(); }
+        }
+        if (rc != GMRM_OK) return fail(rc, keep);
+        if (n > 1)
+            for (int t = 0; t < T; t++) {
+                for (int r = 0; r < n; r++)
+                    if (int rc3 = gmrm_eps_delta_export(g->ctx[r], t, g->q[r])) return rc3;
+                if (int rc3 = allreduce_q(g)) return rc3;
+                for (int r = 0; r < n; r++)
+                    if (int rc3 = gmrm_eps_delta_import(g->ctx[r], t, g->q[r])) return rc3;
+            }
+    }
+    std::vector<int> cass((size_t)T * G * K, 0), c1((size_t)T * G * K);
+    std::vector<double> bsq((size_t)T * G, 0.0), b1((size_t)T * G);
+    for (int r = 0; r < n; r++) {
+        if (int rc3 = gmrm_sampler_end_sweep(g->smp[r], c1.data(), b1.data())) return rc3;
+        for (size_t i = 0; i < cass.size(); i++) cass[i] += c1[i];
+        for (size_t i = 0; i < bsq.size(); i++) bsq[i] += b1[i];                        // shard order, as a sequential MPI_SUM would
+    }
+    for (int r = 0; r < n; r++)
+        if (int rc3 = gmrm_sampler_epilogue(g->smp[r], cass.data(), bsq.data())) return rc3;
+    for (int t = 0; t < T; t++) {
+        gmrm_hyper h;
+        if (int rc3 = gmrm_sampler_get(g->smp[0], t, &h)) return rc3;
+        for (int r = 1; r < n; r++)
+            if (int rc3 = gmrm_sampler_adopt(g->smp[r], t, h.sigmag, h.pi_est, h.sigmae)) return rc3;
     }
     return GMRM_OK;
 }

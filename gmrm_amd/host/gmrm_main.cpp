@@ -43,7 +43,7 @@ struct Opts {
     bool no_rccl = false;
     unsigned ckp_every = 0;       // --checkpoint-every n: write <out-dir>/gmrm.<shard>.ckp after every n-th iteration (this build only)
     bool resume = false;          // --resume: continue from those checkpoints instead of starting over (this build only)
-    unsigned sync_every = 0;      // --sync-every 1: the reference's per-step exchange (bayes.cpp:495-553); 0 = once per sweep (this build only)
+    unsigned sync_every = 0;      // --sync-every 1: the reference's per-step exchange (bayes.cpp:495-553); 0 = once per sweep; k > 1: every k markers (this build only)
 };
 
 [[noreturn]] void fatal(const std::string& m) {
@@ -140,8 +140,9 @@ Opts parse(int argc, char** argv) {
         else if (a == "--resume") { o.resume = true; ss << "--resume 1\n"; }
         else if (a == "--sync-every") {
             last(i);
-            o.sync_every = (unsigned)atoi(argv[++i]);
-            if (o.sync_every > 1) fatal("FATAL  : --sync-every takes 1 (exchange after every marker step, as upstream) or 0 (once per sweep)");
+            const int v = atoi(argv[++i]);
+            if (v < 0) fatal("FATAL  : --sync-every takes 1 (exchange after every marker step, as upstream), 0 (once per sweep) or k > 1 (every k markers of a shard's block)");
+            o.sync_every = (unsigned)v;
             ss << "--sync-every " << o.sync_every << "\n";
         }
         else fatal("FATAL: option \"" + a + "\" unknown");
@@ -484,11 +485,16 @@ int main(int argc, char** argv) {
                nsh, nsh > 1 ? "s" : "", nsh);
     } else if (nsh > 1) {                                                    // replaces the MPI calls of Bayes::process
         need(gmrm_group_create(&grp, nsh, ctxs.data(), smps.data(), G, K, opt.no_rccl ? 0 : 1), "gmrm_group_create");
+        if (opt.sync_every > 1)
+            printf("INFO   : %d marker shards, residual exchange every %u markers of a shard's block through %s.\n", nsh, opt.sync_every,
+                   gmrm_group_uses_rccl(grp) ? "RCCL (ncclAllReduce)" : "host memory");
+        else
         printf("INFO   : %d marker shards, residual exchange once per sweep through %s.\n", nsh,
                gmrm_group_uses_rccl(grp) ? "RCCL (ncclAllReduce)" : "host memory");
         // the sweep-synchronous schedule is an approximation of the sequential scan, not the
         // reference's per-step exchange (bayes.cpp:495-553) -- say so instead of running it silently.
-        printf("WARNING: %d shards sweep their blocks against per-shard residual replicas that are reconciled ONCE per sweep.\n"
+        printf("WARNING: %d shards sweep their blocks against per-shard residual replicas that are reconciled ONCE per sweep (or every\n"
+               "       : --sync-every k markers).\n"
                "       : This is not the Markov chain of `mpiexec -n %d gmrm` (exchange after every marker step) nor the 1-shard chain;\n"
                "       : markers in LD that sit in different shards see each other's updates one sweep late.  Use 1 shard for the\n"
                "       : reference's 1-task chain, or --sync-every 1 for its %d-task chain (slow: one exchange per marker step).\n",
@@ -510,6 +516,7 @@ int main(int argc, char** argv) {
         const double ts = now();
         printf("\n\n@@@ ITERATION %5d\n", it);
         if (grp && opt.sync_every == 1) need(gmrm_group_iterate_steps(grp, (int)it), "gmrm_group_iterate_steps");
+        else if (grp && opt.sync_every > 1) need(gmrm_group_iterate_parts(grp, (int)it, (int)opt.sync_every), "gmrm_group_iterate_parts");
         else if (grp) need(gmrm_group_iterate(grp, (int)it), "gmrm_group_iterate");
         else need(gmrm_sampler_iterate(smp, (int)it), "gmrm_sampler_iterate");
         for (int t = 0; t < T; t++) {

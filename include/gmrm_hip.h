@@ -300,6 +300,9 @@ typedef struct gmrm_group gmrm_group;
 int gmrm_group_create(gmrm_group** out, int n, gmrm_ctx** ctxs, gmrm_sampler** smps, int G, int K, int want_rccl);
 int gmrm_group_uses_rccl(const gmrm_group* g);
 int gmrm_group_iterate(gmrm_group* g, int it);
+/* ... with the residual exchange every k marker positions instead of once per sweep (`--sync-every k`, 1 < k < M; this
+ * build only -- upstream exchanges after every marker step: gmrm_group_iterate_steps).  k >= M: gmrm_group_iterate's chain. */
+int gmrm_group_iterate_parts(gmrm_group* g, int it, int k);
 /* the same iteration on the reference's per-step schedule (see gmrm_sampler_step): the chain of
  * `mpiexec -n <shards> gmrm`, at the reference's cost of one exchange per marker step */
 int gmrm_group_iterate_steps(gmrm_group* g, int it);

@@ -834,6 +834,62 @@ void orc_ns_iterate(orc_chain** ch, int R, int it) {
     free(start); free(s1); free(s2); free(cass); free(bsq);
 }
 
+/* orc_ns_iterate with the residual exchange every k marker positions instead of once per sweep (the build's
+ * `--sync-every k`, 1 < k < M; no upstream counterpart -- upstream exchanges after every marker, orc_ps_iterate):
+ * part p = positions [p k, (p + 1) k) of every rank's own visit order, swept against the rank's own replica; behind
+ * every part the replicas are reconciled as in step 3 of orc_ns_iterate.  k >= max M_r is orc_ns_iterate. */
+void orc_nk_iterate(orc_chain** ch, int R, int it, int k) {
+    const int n4 = 4 * ch[0]->im4, G = ch[0]->G, K = ch[0]->K;
+    double mu0 = 0.0;
+    for (int r = 0; r < R; r++) {
+        double mu_r = orc_chain_prologue_draw(ch[r], it);
+        if (r == 0) mu0 = mu_r;
+    }
+    int Mm = 0;
+    for (int r = 0; r < R; r++) {
+        orc_chain_prologue_apply(ch[r], mu0);
+        if (ch[r]->M > Mm) Mm = ch[r]->M;
+    }
+    double* start = (double*)malloc(sizeof(double) * (size_t)n4);
+    double* s1 = (double*)malloc(sizeof(double) * (size_t)n4);
+    double* s2 = (double*)malloc(sizeof(double) * (size_t)n4);
+    for (int first = 0; first < Mm; first += k) {
+        memcpy(start, ch[0]->eps, sizeof(double) * (size_t)n4);
+        memset(s1, 0, sizeof(double) * (size_t)n4);
+        memset(s2, 0, sizeof(double) * (size_t)n4);
+        for (int r = 0; r < R; r++) {
+            const int end = first + k < ch[r]->M ? first + k : ch[r]->M;
+            for (int mrki = first; mrki < end; mrki++) chain_marker_step(ch[r], ch[r]->midx[mrki]);
+            for (int i = 0; i < n4; i++) {
+                double q1, q2;
+                orc_split2(ch[r]->eps[i] - start[i], &q1, &q2);
+                s1[i] += q1; s2[i] += q2;
+            }
+        }
+        if (R > 1)
+            for (int r = 0; r < R; r++)
+                for (int i = 0; i < n4; i++) ch[r]->eps[i] = start[i] + (s1[i] + s2[i]);
+    }
+    int* cass = (int*)calloc((size_t)(G * K), sizeof(int));
+    double* bsq = (double*)calloc((size_t)G, sizeof(double));
+    for (int r = 0; r < R; r++) {
+        orc_chain_local_sums(ch[r]);
+        for (int i = 0; i < G * K; i++) cass[i] += ch[r]->cass[i];
+        for (int g = 0; g < G; g++) bsq[g] += ch[r]->beta_sqn[g];
+    }
+    for (int r = 0; r < R; r++) {
+        memcpy(ch[r]->cass, cass, sizeof(int) * (size_t)(G * K));
+        memcpy(ch[r]->beta_sqn, bsq, sizeof(double) * (size_t)G);
+        orc_chain_epilogue(ch[r]);
+    }
+    for (int r = 1; r < R; r++) {
+        memcpy(ch[r]->sigmag, ch[0]->sigmag, sizeof(double) * (size_t)G);
+        memcpy(ch[r]->pi_est, ch[0]->pi_est, sizeof(double) * (size_t)(G * K));
+        ch[r]->sigmae = ch[0]->sigmae;
+    }
+    free(start); free(s1); free(s2); free(cass); free(bsq);
+}
+
 /* The reference's own schedule for R ranks holding disjoint marker shards of ONE phenotype
  * (bayes.cpp:340-651 read as R MPI tasks in one loop):
  *   prologue  every rank draws AND uses its own mu from its own stream (bayes.cpp:348-358; seeds :796-803),

@@ -110,6 +110,8 @@ void orc_ns_iterate(orc_chain** chains, int nranks, int it);
 /* the reference's own per-step multi-rank schedule (bayes.cpp:374-553, 681-706): every rank keeps its own mu,
  * after every marker step all replicas apply the changed markers of all ranks in rank order. */
 void orc_ps_iterate(orc_chain** chains, int nranks, int it);
+/* orc_ns_iterate with the residual exchange every k marker positions (the build's --sync-every k; no upstream counterpart) */
+void orc_nk_iterate(orc_chain** chains, int nranks, int it, int k);
 
 /* getters (pointers stay owned by the chain) */
 double* orc_chain_eps(orc_chain* c);

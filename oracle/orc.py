@@ -89,6 +89,7 @@ _SIGS = {
     "orc_chain_epilogue": (None, [C.c_void_p]),
     "orc_ns_iterate": (None, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "orc_ps_iterate": (None, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "orc_nk_iterate": (None, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
     "orc_chain_eps": (c_double_p, [C.c_void_p]),
     "orc_chain_betas": (c_double_p, [C.c_void_p]),
     "orc_chain_acum": (c_double_p, [C.c_void_p]),
@@ -240,6 +241,12 @@ def ns_iterate(chains, it):
     """The build's sweep-synchronous multi-rank schedule (orc_ns_iterate)."""
     arr = (C.c_void_p * len(chains))(*[c.h for c in chains])
     chains[0].L.orc_ns_iterate(arr, len(chains), int(it))
+
+
+def nk_iterate(chains, it, k):
+    """orc_ns_iterate with the residual exchange every k marker positions (orc_nk_iterate)."""
+    arr = (C.c_void_p * len(chains))(*[c.h for c in chains])
+    chains[0].L.orc_nk_iterate(arr, len(chains), int(it), int(k))
 
 
 def ps_iterate(chains, it):

@@ -77,7 +77,7 @@ def prepare_traits(inp):
 
 
 def run_oracle(case: Case, inp, iters=None, canon=True, nranks=1, seed=None, shuffle=True, mimic_hydra=False,
-               schedule="sweep"):
+               schedule="sweep", sync_every=0):
     """History of the oracle chain(s): per trait, per iteration comp / betas / hyper-parameters.
     schedule: "sweep" = the build's once-per-sweep exchange (orc_ns_iterate), "steps" = the reference's exchange
     after every marker step (orc_ps_iterate, bayes.cpp:495-553); they coincide for nranks == 1."""
@@ -98,6 +98,8 @@ def run_oracle(case: Case, inp, iters=None, canon=True, nranks=1, seed=None, shu
         for it in range(1, iters + 1):
             if schedule == "steps":
                 orc.ps_iterate(chains, it)
+            elif sync_every:                                     # the residual exchange every sync_every markers (orc_nk_iterate)
+                orc.nk_iterate(chains, it, sync_every)
             elif nranks == 1:
                 chains[0].iterate(it)
             else:

@@ -101,6 +101,41 @@ def test_cli_marker_shards_in_one_process(gpu, tmp_path, name, shards):
         assert Path(str(stem) + ".csv").read_bytes() == csv
 
 
+@pytest.mark.parametrize("name,shards,k", [("ragged", 2, 40), ("k3", 3, 7), ("groups", 2, 100), ("ragged", 2, 1000)])
+def test_cli_residual_exchange_every_k_markers(gpu, tmp_path, name, shards, k):
+    """bin/gmrm_hip --devices 0,0[,0] --sync-every k (1 < k): the shards sweep k markers of their blocks, exchange their
+    residual deltas (the same exact all-reduce as once per sweep), and go on -- gmrm_group_iterate_parts on top of the sweep
+    kernel's part launches.  Blocks of different lengths (the last part of one shard is shorter, or empty), a k that does
+    not divide the block, a k beyond the block (one part: the once-per-sweep chain).  Byte for byte against the oracle's
+    statement of the schedule (orc_nk_iterate)."""
+    assert BIN.exists(), "bin/gmrm_hip not built (python __graft_entry__.py)"
+    case = cases.CASE_BY_NAME[name]
+    inp = cases.make_inputs(case)
+    inp["cva"] = np.array([[float(f"{v:.5f}") for v in row] for row in inp["cva"]])
+    phens = _write_inputs(tmp_path, case, inp)
+    out = tmp_path / "out"
+    iters = 3
+    cmd = [str(BIN), "--bed-file", str(tmp_path / "t.bed"), "--dim-file", str(tmp_path / "t.dim"),
+           "--phen-files", ",".join(str(p) for p in phens), "--group-index-file", str(tmp_path / "t.gri"),
+           "--group-mixture-file", str(tmp_path / "t.grm"), "--shuffle-markers", "1", "--seed", str(case.seed),
+           "--iterations", str(iters), "--out-dir", str(out), "--devices", ",".join(["0"] * shards), "--sync-every", str(k)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert f"{shards} marker shards, residual exchange every {k} markers" in r.stdout
+    want = cases.run_oracle(case, inp, iters=iters, canon=True, nranks=shards, sync_every=k)
+    once = cases.run_oracle(case, inp, iters=iters, canon=True, nranks=shards)
+    for t, h in enumerate(want):
+        stem = out / f"trait{t}"
+        bet = b"".join([struct.pack("<I", case.M)] + [struct.pack("<I", it) + h["betas"][it - 1].tobytes() for it in range(1, iters + 1)])
+        cpn = b"".join([struct.pack("<I", case.M)] + [struct.pack("<I", it) + h["comp"][it - 1].astype("<i4").tobytes() for it in range(1, iters + 1)])
+        csv = b"".join(h["csv"][it - 1] for it in range(1, iters + 1))
+        assert Path(str(stem) + ".bet").read_bytes() == bet
+        assert Path(str(stem) + ".cpn").read_bytes() == cpn
+        assert Path(str(stem) + ".csv").read_bytes() == csv
+        same = all(np.array_equal(a, b) for a, b in zip(h["betas"], once[t]["betas"]))
+        assert same == (k >= 1000)                                # k beyond the blocks is the once-per-sweep chain; a real k is another chain
+
+
 @pytest.mark.parametrize("name,shards", [("ragged", 2), ("k3", 3), ("small", 1)])
 def test_cli_per_step_schedule_is_the_reference_multi_task_chain(gpu, tmp_path, name, shards):
     """bin/gmrm_hip --sync-every 1: the exchange after every marker step that upstream runs (bayes.cpp:495-553,
