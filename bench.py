@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline time")
     ap.add_argument("--no-signal", action="store_true", help="skip the signal-bearing extra block")
     ap.add_argument("--signal-sweeps", type=int, default=8, help="sweeps of the signal-bearing chain (first 2 reported apart)")
+    ap.add_argument("--sync-every", type=int, default=0, help="residual exchange every k markers of a shard's block instead of once per "
+                                                              "sweep (the sweep runs as ceil(M/k) kernel launches); 0 = once per sweep")
     return ap.parse_args()
 
 
@@ -243,9 +245,9 @@ def main():
 
     def step(it):
         if driver is not None:
-            driver.iterate(it)
+            driver.iterate(it, sync_every=a.sync_every)
         else:
-            smp.iterate(it)
+            smp.iterate_parts(it, a.sync_every) if a.sync_every > 0 else smp.iterate(it)
 
     def fence():
         if use_pg:
@@ -312,7 +314,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {N} individuals x {Mt} SNPs, {T} phenotype(s), {G} group(s), "
                                    f"K=4, genotypes Binomial(2,0.4) generated on device, y~N(0,1), seed {a.seed}",
-                       "markers_per_gpu": M, "parallelism": f"marker-shard x{world}, 1 residual all-reduce/sweep",
+                       "markers_per_gpu": M, "parallelism": f"marker-shard x{world}, 1 residual all-reduce/sweep" if a.sync_every <= 0 else
+                                                            f"marker-shard x{world}, 1 residual all-reduce every {a.sync_every} markers",
                        "phenotype_na_rate": na_rate, "genotype_missing_rate": miss,
                        "markers_with_missing_genotypes": dirty_frac if dirty_frac else (1.0 if miss > 0 else 0.0)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -327,6 +327,10 @@ class Sampler:
     def finish_part(self):
         check(self.lib.gmrm_sampler_finish_part(self.h))
 
+    def preshuffle(self):
+        """The NEXT iteration's marker shuffle, on the idle host while a part is in flight (gmrm_sampler_preshuffle)."""
+        check(self.lib.gmrm_sampler_preshuffle(self.h))
+
     def iterate_parts(self, it, k):
         """One iteration of a single shard with the sweep cut into parts of k markers: the same chain as iterate()."""
         mu = self.draw_mu(it)
@@ -336,6 +340,8 @@ class Sampler:
         while True:
             n = min(int(k), M - first)
             self.launch_part(first, n)
+            if first == 0:
+                self.preshuffle()
             self.finish_part()
             first += n
             if first >= M:

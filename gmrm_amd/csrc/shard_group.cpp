@@ -225,7 +225,7 @@ extern "C" int gmrm_group_iterate(gmrm_group* g, int it) {
 }
 
 // gmrm_group_iterate with the residual exchange every k marker positions instead of once per sweep (`--sync-every k`,
-// 1 < k < M; oracle: orc_nk_iterate): part p = positions [p k, (p + 1) k) of every shard's own visit order, all shards'
+// 1 < k < M): part p = positions [p k, (p + 1) k) of every shard's own visit order, all shards'
 // parts in flight together, the replicas reconciled behind every part (the same exact all-reduce of the deltas).
 extern "C" int gmrm_group_iterate_parts(gmrm_group* g, int it, int k) {
     if (!g) return fail(GMRM_EINVAL, "null group");
@@ -246,6 +246,11 @@ extern "C" int gmrm_group_iterate_parts(gmrm_group* g, int it, int k) {
             rc = gmrm_sampler_launch_part(g->smp[r], f, std::min(k, Mr - f));           // launches; returns at once
         }
         std::string keep = rc != GMRM_OK ? gmrm_last_error() : "";
+        if (first == 0 && rc == GMRM_OK)                                                // the next iteration's shuffles, beside the first parts
+            for (int r = 0; r < n && rc == GMRM_OK; r++) {
+                rc = gmrm_sampler_preshuffle(g->smp[r]);
+                if (rc != GMRM_OK) keep = gmrm_last_error();
+            }
         for (int r = 0; r < n; r++) {                                                   // always: what is in flight must be collected
             const int rc2 = gmrm_sampler_finish_part(g->smp[r]);
             if (rc == GMRM_OK && rc2 != GMRM_OK) { rc = rc2; keep = gmrm_last_error(); }

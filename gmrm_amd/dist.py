@@ -16,6 +16,10 @@ reconciled ONCE per sweep (DESIGN.md "Multi-GPU"):
   5. every rank runs the hyper-parameter draws on its own stream, then adopts  (src/bayes.cpp:626,638,649)
      rank 0's sigmag / pi_est / sigmae
 
+iterate(it, sync_every=k) with k > 0 cuts steps 2-3 into parts of k marker positions: every rank sweeps positions
+[p k, (p + 1) k) of its own visit order, then the replicas are reconciled (step 3), and so on to the end of the longest
+block -- between the once-per-sweep exchange and the reference's exchange after every marker (`--sync-every k`).
+
 `engine` is anything with the Sampler/Context split-call surface (gmrm_amd.api); the CPU
 tests drive this same code with a stand-in engine to check the exchange logic under gloo.
 """
@@ -36,6 +40,7 @@ class HipEngine:
         self.n4 = 4 * self.ctx.mbytes
         self.device = device
         self.host_staging = host_staging
+        self.M = self.ctx.M
         self._q = torch.empty(2 * self.n4, dtype=torch.float64, device=device)
 
     def draw_mu(self, it):
@@ -46,6 +51,18 @@ class HipEngine:
 
     def end_sweep(self):
         return self.s.end_sweep()
+
+    def begin_parts(self, mu):
+        self.s.begin_parts(mu)
+
+    def launch_part(self, first, count):
+        self.s.launch_part(first, count)
+
+    def finish_part(self):
+        self.s.finish_part()
+
+    def preshuffle(self):
+        self.s.preshuffle()
 
     def delta_export(self, t):
         torch.cuda.current_stream(self.device).synchronize()
@@ -79,19 +96,42 @@ class ShardedDriver:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self._mmax = None
 
-    def iterate(self, it):
+    def _exchange(self):
+        e = self.e
+        for t in range(e.T):
+            q = e.delta_export(t)
+            dist.all_reduce(q, op=dist.ReduceOp.SUM, group=self.group)
+            e.delta_import(t, q)
+
+    def iterate(self, it, sync_every=0):
         e = self.e
         T, G, K = e.T, e.G, e.K
         mu = e.small(np.asarray(e.draw_mu(it), dtype=np.float64))
         dist.broadcast(mu, src=0, group=self.group)
-        e.begin_sweep(mu.cpu().numpy())
-        cass, bsq = e.end_sweep()
-        if self.world > 1:                              # one shard: nothing to reconcile (exactly the
-            for t in range(T):                          # reference's single-rank chain)
-                q = e.delta_export(t)
-                dist.all_reduce(q, op=dist.ReduceOp.SUM, group=self.group)
-                e.delta_import(t, q)
+        if sync_every and sync_every > 0:
+            if self._mmax is None:                      # the longest block decides how many parts a sweep has
+                m = e.small(np.asarray([e.M], dtype=np.int64))
+                dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+                self._mmax = int(m.cpu().numpy()[0])
+            e.begin_parts(mu.cpu().numpy())
+            first = 0
+            while first < self._mmax:
+                f = min(first, e.M)
+                e.launch_part(f, min(int(sync_every), e.M - f))
+                if first == 0:
+                    e.preshuffle()                      # the next iteration's shuffle, beside the first part
+                e.finish_part()
+                if self.world > 1:
+                    self._exchange()
+                first += int(sync_every)
+            cass, bsq = e.end_sweep()
+        else:
+            e.begin_sweep(mu.cpu().numpy())
+            cass, bsq = e.end_sweep()
+            if self.world > 1:                          # one shard: nothing to reconcile (exactly the
+                self._exchange()                        # reference's single-rank chain)
         cass_t = e.small(np.ascontiguousarray(cass, dtype=np.int32))
         dist.all_reduce(cass_t, op=dist.ReduceOp.SUM, group=self.group)
         bsq_t = e.small(np.ascontiguousarray(bsq, dtype=np.float64))

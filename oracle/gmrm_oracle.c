@@ -739,6 +739,11 @@ void orc_chain_markers(orc_chain* c) {
     for (int mrki = 0; mrki < c->M; mrki++) chain_marker_step(c, c->midx[mrki]);
 }
 
+/* positions [first, first + count) of the visit order (a part of the sweep: orc_nk_iterate, the build's --sync-every k) */
+void orc_chain_markers_range(orc_chain* c, int first, int count) {
+    for (int mrki = first; mrki < first + count && mrki < c->M; mrki++) chain_marker_step(c, c->midx[mrki]);
+}
+
 /* bayes.cpp:565-568 */
 void orc_chain_local_sums(orc_chain* c) {
     for (int g = 0; g < c->G; g++) c->beta_sqn[g] = 0.0;

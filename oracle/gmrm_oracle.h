@@ -102,6 +102,7 @@ void orc_chain_prologue(orc_chain* c, int it);     /* bayes.cpp:348-368 */
 double orc_chain_prologue_draw(orc_chain* c, int it);      /* :348-358, returns the drawn mu */
 void   orc_chain_prologue_apply(orc_chain* c, double mu);  /* :358-367 */
 void orc_chain_markers(orc_chain* c);              /* bayes.cpp:375-553, own markers only */
+void orc_chain_markers_range(orc_chain* c, int first, int count);   /* a part of the visit order */
 void orc_chain_local_sums(orc_chain* c);           /* bayes.cpp:565-568 (beta_sqn), cass stays local */
 void orc_chain_epilogue(orc_chain* c);             /* bayes.cpp:590-651 */
 /* the build's sweep-synchronous multi-rank schedule (DESIGN.md "Multi-GPU"); not the

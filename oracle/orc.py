@@ -85,6 +85,7 @@ _SIGS = {
     "orc_chain_prologue_draw": (C.c_double, [C.c_void_p, C.c_int]),
     "orc_chain_prologue_apply": (None, [C.c_void_p, C.c_double]),
     "orc_chain_markers": (None, [C.c_void_p]),
+    "orc_chain_markers_range": (None, [C.c_void_p, C.c_int, C.c_int]),
     "orc_chain_local_sums": (None, [C.c_void_p]),
     "orc_chain_epilogue": (None, [C.c_void_p]),
     "orc_ns_iterate": (None, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),

@@ -35,6 +35,7 @@ class OracleEngine:
         self.L = self.ch.L
         self.T, self.G, self.K = 1, self.ch.G, self.ch.K
         self.n4 = 4 * self.ch.n4
+        self.M = Ml
         self.start = None
 
     def _eps_view(self):
@@ -47,6 +48,19 @@ class OracleEngine:
         self.L.orc_chain_prologue_apply(self.ch.h, float(mu[0]))
         self.start = self._eps_view().copy()
         self.L.orc_chain_markers(self.ch.h)
+
+    def begin_parts(self, mu):
+        self.L.orc_chain_prologue_apply(self.ch.h, float(mu[0]))
+
+    def launch_part(self, first, count):
+        self.start = self._eps_view().copy()
+        self.L.orc_chain_markers_range(self.ch.h, int(first), int(count))
+
+    def finish_part(self):
+        pass
+
+    def preshuffle(self):
+        pass
 
     def end_sweep(self):
         self.L.orc_chain_local_sums(self.ch.h)
@@ -85,7 +99,7 @@ class OracleEngine:
         return torch.as_tensor(np.asarray(arr))
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, sync_every=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gmrm_amd.dist import ShardedDriver
@@ -95,7 +109,7 @@ def _worker(rank, world, port, outdir):
     eng = OracleEngine(case, inp, rank, world)
     drv = ShardedDriver(eng)
     for it in range(1, 4):
-        drv.iterate(it)
+        drv.iterate(it, sync_every=sync_every)
     np.savez(Path(outdir) / f"rank{rank}.npz", betas=eng.ch.betas, comp=eng.ch.comp, eps=eng.ch.eps,
              sigmae=eng.ch.sigmae, sigmag=eng.ch.sigmag, pi=eng.ch.pi_est)
     dist.destroy_process_group()
@@ -122,4 +136,25 @@ def test_two_ranks_reproduce_the_schedule(tmp_path):
         assert np.array_equal(x["eps"], want["eps"])
         assert float(x["sigmae"]) == want["sigmae"][-1]
         assert np.array_equal(x["sigmag"], want["sigmag"][-1])
+        assert np.array_equal(x["pi"], want["pi"][-1])
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,k", [(2, 23), (3, 7)])
+def test_ranks_reproduce_the_exchange_every_k_markers(tmp_path, world, k):
+    """ShardedDriver.iterate(it, sync_every=k): blocks of different lengths (k3: 200 markers over 3 ranks), a k that does not
+    divide them; bit for bit the single-process statement of the schedule (orc_nk_iterate), and not the once-per-sweep chain."""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), k), nprocs=world, join=True)
+    from tests import cases
+    case = cases.CASE_BY_NAME["k3"]
+    inp = cases.make_inputs(case)
+    want = cases.run_oracle(case, inp, iters=3, canon=True, nranks=world, sync_every=k)[0]
+    once = cases.run_oracle(case, inp, iters=3, canon=True, nranks=world)[0]
+    r = [np.load(tmp_path / f"rank{j}.npz") for j in range(world)]
+    assert np.array_equal(np.concatenate([x["betas"] for x in r]), want["betas"][-1])
+    assert np.array_equal(np.concatenate([x["comp"] for x in r]), want["comp"][-1])
+    assert not np.array_equal(want["betas"][-1], once["betas"][-1])
+    for x in r:
+        assert np.array_equal(x["eps"], want["eps"])
+        assert float(x["sigmae"]) == want["sigmae"][-1]
         assert np.array_equal(x["pi"], want["pi"][-1])
