@@ -136,7 +136,7 @@ def test_full_width_properties(gpu):
     smp.close(); ctx.close()
 
 
-def _sharded_worker(rank, world, port, outdir, name):
+def _sharded_worker(rank, world, port, outdir, name, sync_every=0):
     import os
     import torch
     import torch.distributed as dist
@@ -153,7 +153,7 @@ def _sharded_worker(rank, world, port, outdir, name):
     smp = gmrm_amd.Sampler(ctx, case.seed, inp["cva"], inp["group_index"], rank=rank, nranks=world)
     drv = ShardedDriver(HipEngine(smp, torch.device("cuda", 0), host_staging=True))
     for it in range(1, 4):
-        drv.iterate(it)
+        drv.iterate(it, sync_every=sync_every)
     hy = smp.hyper(0)
     np.savez(f"{outdir}/rank{rank}.npz", betas=ctx.betas(0), comp=ctx.comp(0), eps=ctx.get_epsilon(0),
              sigmae=hy.sigmae, sigmag=hy.sigmag, pi=hy.pi_est)
@@ -161,22 +161,23 @@ def _sharded_worker(rank, world, port, outdir, name):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["k3", "ragged"])
-def test_marker_sharded_schedule_two_ranks(gpu, tmp_path, name):
+@pytest.mark.parametrize("name,k", [("k3", 0), ("ragged", 0), ("ragged", 33)])
+def test_marker_sharded_schedule_two_ranks(gpu, tmp_path, name, k):
     """The multi-GPU path end to end on one GPU: two processes (gloo, tensors staged through
     the host because both ranks share device 0), each sweeping its marker block with the HIP
-    kernel and exchanging the exact residual deltas once per sweep -- against the oracle's
-    single-process statement of the same schedule (orc_ns_iterate), bit for bit."""
+    kernel and exchanging the exact residual deltas once per sweep -- or, k > 0, every k markers (`--sync-every k`:
+    part launches of the sweep kernel) -- against the oracle's single-process statement of the same schedule
+    (orc_ns_iterate / orc_nk_iterate), bit for bit."""
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     world = 2
-    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), name), nprocs=world, join=True)
+    mp.spawn(_sharded_worker, args=(world, port, str(tmp_path), name, k), nprocs=world, join=True)
     case = cases.CASE_BY_NAME[name]
     inp = cases.make_inputs(case)
-    want = cases.run_oracle(case, inp, iters=3, canon=True, nranks=world)[0]
+    want = cases.run_oracle(case, inp, iters=3, canon=True, nranks=world, sync_every=k)[0]
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
     assert np.array_equal(np.concatenate([x["comp"] for x in r]), want["comp"][-1])
     assert np.array_equal(np.concatenate([x["betas"] for x in r]), want["betas"][-1])
