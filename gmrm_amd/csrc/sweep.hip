@@ -233,6 +233,9 @@ struct Spin {
     unsigned n;
     __device__ __forceinline__ void start(unsigned long long lim) { t0 = __builtin_amdgcn_s_memrealtime(); limit = lim; n = 0; }
     __device__ __forceinline__ bool expired(unsigned* abort_word) {
+#ifndef GM_SCREEN
+#define GM_SCREEN 1
+#endif
 #ifndef GM_POLL_SLEEP
 #define GM_POLL_SLEEP 1
 #endif
@@ -519,6 +522,7 @@ struct Walk {
     int ndone;
     bool stopped, planned;
     bool repeek;         // a stop consumed words of the stream: the prepared draws no longer hold
+    bool screen;         // the recent runs are long: try the cheap certain bound before the exact probabilities (walk_piece)
     // a stop the walk may cross, met by the first piece and left to the second: its index among the batch's crossable
     // markers (or -1), its position, the two values of its update in grid units and its sum of genotype values
     int q, at;
@@ -620,15 +624,43 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, T
         double muk[K], logl[K];
 #pragma unroll
         for (int i = 0; i < K; i++) { muk[i] = 0.0; logl[i] = 0.0; }
+        double num = 0.0;
         if (use) {
             const double dpa = tt.t0 + tt.t1, dpb = tt.t2 + tt.t3;
-            double num = in.msig * (dpa - in.mave * dpb);               // bayes.cpp:765
+            num = in.msig * (dpa - in.mave * dpb);                       // bayes.cpp:765
             num += beta_old * nm1;                                       // bayes.cpp:421
-            acum_v = decide0<K>(num, tb, inv2sige, muk, logl);
         }
+        // Screen: in most passes every marker stays in component 0 by a wide margin (acum0 ~ 0.99, the draw uniform), and the
+        // exact probability -- three f64 divisions, three exp_ chains and a fourth division per lane -- is needed only to SAY so.
+        // A bound that is cheap and certain does as well: S~ = sum_i exp(d~_i) from one f64 fma per component (the
+        // reciprocal of denom from v_rcp_f64) and v_exp_f32, within 1e-4 of the exact sum; if
+        //     draw * (1 + 1.002 S~) <= 0.999999
+        // then draw <= 1 / (1 + S) = acum0 as the exact arithmetic rounds it, whatever its last bits are.  A lane that is
+        // not certain (the draw within ~0.2 % of acum0, an effect that was non-zero, |d| near the 700 cut-off, anything not
+        // finite) sends the whole pass through the exact code below -- same chain, bit for bit, either way.
+        bool screened = false;                                           // (uniform)
+#if GM_SCREEN
+        if (w.screen) {                                                  // (uniform; at high update rates nearly every pass holds a stop: skip the attempt)
+            bool sure = true;
+            if (use) {
+                const double n2 = num * num;
+                float sf = 0.f;
+                bool okd = beta_old == 0.0;
+#pragma unroll
+                for (int i = 1; i < K; i++) {
+                    const double dt = (tb.logpi[i] - tb.logpi[0]) + (tb.mhl[i] + n2 * (inv2sige * __builtin_amdgcn_rcp(tb.denom[i])));
+                    okd = okd && (fabs(dt) < 690.0);                     // (false for NaN)
+                    sf += __builtin_amdgcn_exp2f((float)dt * 1.44269504f);
+                }
+                sure = okd && (prob * (1.0 + 1.002 * (double)sf) <= 0.999999);
+            }
+            screened = __ballot(act && !sure) == 0ull;
+        }
+#endif
+        if (!screened && use) acum_v = decide0<K>(num, tb, inv2sige, muk, logl);
         SSTAMP(1);   // decide0
         // a lane whose draw exceeds acum0 ends in a component > 0 (bayes.cpp:451,476): it stops the walk
-        const bool stop = use && (!(prob <= acum_v) || beta_old != 0.0);
+        const bool stop = !screened && use && (!(prob <= acum_v) || beta_old != 0.0);
         const unsigned long long stop_mask = __ballot(stop);
         const int s = stop_mask ? (__ffsll((long long)stop_mask) - 1) : nbp;
         const int n_done = s < nbp ? s + 1 : nbp;
@@ -646,9 +678,9 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, T
         SSTAMP(2);   // component search
         if (act && lane < n_done && lane != s) {
             if (sig0) {
-                if (writer) { out.acum[m] = 1.0; out.betas_out[m] = 0.0; }
+                if (writer) out.betas_out[m] = 0.0;
             } else if (writer) {                                         // component 0, effect stays 0
-                out.acum[m] = acum_v; out.betas_out[m] = 0.0; out.comp[m] = 0;
+                out.betas_out[m] = 0.0; out.comp[m] = 0;
                 atomicAdd(&s_cass[g * K + 0], 1);
             }
         }
@@ -680,7 +712,7 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, T
                 ul.pos[nupd] = base + s;
             }
             if (writer) {
-                out.acum[m] = acum_v; out.betas_out[m] = beta_new; out.comp[m] = kc;
+                out.betas_out[m] = beta_new; out.comp[m] = kc;
                 atomicAdd(&s_cass[g * K + kc], 1);
             }
             cur_s = rs.cursor;
@@ -736,6 +768,7 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
     Walk w;
     w.cursor = ctl[C_CURSOR]; w.run = 2 * nb; w.nupd = 0; w.ncross = 0; w.from = 0; w.ndone = nb;
     w.stopped = false; w.planned = false; w.repeek = false; w.q = -1; w.at = 0; w.ai = 0; w.bi = 0; w.xs = 0;
+    w.screen = ctl[C_EMA] >= 16 * 48;                                // recent run length (1/16 marker): a pass of 64 markers has a fair chance to hold no stop
     walk_piece<K, CK, true>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
     if (CK != 0) {
         if (__builtin_expect(w.q >= 0, 0))                           // (uniform) the walk met a marker it may cross
@@ -1118,8 +1151,77 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
         __syncthreads();
     };
+    // ---- per-marker inputs of the sampling step (marker id, group, previous effect, mave, msig):
+    // wavefront 3 fetches them for upcoming order positions (dependent global loads) one
+    // round ahead and parks them in a 256-position LDS ring, so a restart never waits on them.
+    int* mr_m = reinterpret_cast<int*>(smem + L_META);
+    int* mr_g = mr_m + META_POS;
+    double* mr_beta = reinterpret_cast<double*>(mr_g + META_POS);
+    double* mr_mave = mr_beta + META_POS;
+    double* mr_msig = mr_mave + META_POS;
+    uint8_t* mr_nm = reinterpret_cast<uint8_t*>(smem + L_NM);
+    int mhi = 0, npm = 0;                             // meta ring holds positions [pos, mhi)
+    int pm_m[2] = {0, 0}, pm_g[2] = {0, 0}, pm_nm[2] = {1, 1};
+    double pm_beta[2] = {0.0, 0.0}, pm_mave[2] = {0.0, 0.0}, pm_msig[2] = {1.0, 1.0};
+    // in two steps: the marker ids, then -- once they are there -- what hangs on them.  Between the two the caller waits for
+    // something else (the gate of the column prefetch); the second step goes in FRONT of the column loads: a wait for ids
+    // issued behind those would be a wait for the columns (HBM latency), which kept wavefront 3 from the round's barrier
+    // until after wavefront 0 had finished sampling.
+    auto meta_ids = [&](int want) {
+        if (want > a.M) want = a.M;
+        npm = want - mhi;
+        if (npm > 128) npm = 128;
+        if (npm < 0) npm = 0;
+        if (wave == 3) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (64 * h < npm) {
+                    const int p = mhi + 64 * h + lane;
+                    const int pi = p < a.M ? p : a.M - 1;
+                    pm_m[h] = a.order[pi];
+                }
+            }
+        }
+    };
+    auto meta_issue = [&](int want) {
+        (void)want;
+        if (wave == 3) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (64 * h < npm) {
+                    pm_g[h] = a.group[pm_m[h]];
+                    pm_beta[h] = a.betas_in[pm_m[h]];
+                    pm_mave[h] = a.mave[pm_m[h]];
+                    pm_msig[h] = a.msig[pm_m[h]];
+                    if (MODE == 1) pm_nm[h] = a.nomiss[pm_m[h]];
+                }
+            }
+        }
+    };
+    auto meta_commit = [&]() {
+        int nc = pos + META_POS - mhi;
+        if (nc > npm) nc = npm;
+        if (nc < 0) nc = 0;
+        if (wave == 3) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (64 * h + lane < nc) {
+                    const int sl = (mhi + 64 * h + lane) & (META_POS - 1);
+                    mr_m[sl] = pm_m[h]; mr_g[sl] = pm_g[h]; mr_beta[sl] = pm_beta[h]; mr_mave[sl] = pm_mave[h]; mr_msig[sl] = pm_msig[h];
+                    if (MODE == 1) mr_nm[sl] = (uint8_t)pm_nm[h];
+                }
+            }
+        }
+        mhi += nc;
+        npm = 0;
+    };
+    auto ensure_meta = [&](int upto) {                 // slow path (uniform): meta ring must hold [.., upto)
+        if (mhi < upto) meta_commit();
+        while (mhi < upto) { meta_ids(upto); meta_issue(upto); meta_commit(); }
+    };
+
     // request the slices of positions [hi, want) (at most PFN*PPI); they stay in registers until commit
-    auto prefetch_issue = [&](int want, unsigned gate_tag) {
+    auto prefetch_issue = [&](int want, unsigned gate_tag, const bool with_meta) {
         if (want > a.M) want = a.M;
         npf = want - hi;
         if (npf > PFN * PPI) npf = PFN * PPI;
@@ -1150,6 +1252,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 while (*reinterpret_cast<const volatile int*>(&ctl[C_TOTF]) != (int)gate_tag)
                     if (sp.expired(abort_word)) break;
             }
+            if (with_meta) meta_issue(0);             // (loads that depend on ids requested before the gate: they have landed by now)
             // The column loads are inline asm on AGPR destinations: the compiler neither waits for them nor
             // counts them; the only wait is the explicit one in prefetch_commit, a whole round later
             // (tools/check_prefetch_regs.py checks in the disassembly that nothing touches them in between).
@@ -1202,61 +1305,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     auto ensure = [&](int upto) {                      // slow path: ring must hold [pos, upto)
         if (hi < upto) prefetch_commit();
         if (hi < upto) { fill(hi, upto); hi = upto; }
-    };
-
-    // ---- per-marker inputs of the sampling step (marker id, group, previous effect, mave, msig):
-    // wavefront 3 fetches them for upcoming order positions (dependent global loads) one
-    // round ahead and parks them in a 256-position LDS ring, so a restart never waits on them.
-    int* mr_m = reinterpret_cast<int*>(smem + L_META);
-    int* mr_g = mr_m + META_POS;
-    double* mr_beta = reinterpret_cast<double*>(mr_g + META_POS);
-    double* mr_mave = mr_beta + META_POS;
-    double* mr_msig = mr_mave + META_POS;
-    uint8_t* mr_nm = reinterpret_cast<uint8_t*>(smem + L_NM);
-    int mhi = 0, npm = 0;                             // meta ring holds positions [pos, mhi)
-    int pm_m[2] = {0, 0}, pm_g[2] = {0, 0}, pm_nm[2] = {1, 1};
-    double pm_beta[2] = {0.0, 0.0}, pm_mave[2] = {0.0, 0.0}, pm_msig[2] = {1.0, 1.0};
-    auto meta_issue = [&](int want) {
-        if (want > a.M) want = a.M;
-        npm = want - mhi;
-        if (npm > 128) npm = 128;
-        if (npm < 0) npm = 0;
-        if (wave == 3) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if (64 * h < npm) {
-                    const int p = mhi + 64 * h + lane;
-                    const int pi = p < a.M ? p : a.M - 1;
-                    pm_m[h] = a.order[pi];
-                    pm_g[h] = a.group[pm_m[h]];
-                    pm_beta[h] = a.betas_in[pm_m[h]];
-                    pm_mave[h] = a.mave[pm_m[h]];
-                    pm_msig[h] = a.msig[pm_m[h]];
-                    if (MODE == 1) pm_nm[h] = a.nomiss[pm_m[h]];
-                }
-            }
-        }
-    };
-    auto meta_commit = [&]() {
-        int nc = pos + META_POS - mhi;
-        if (nc > npm) nc = npm;
-        if (nc < 0) nc = 0;
-        if (wave == 3) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if (64 * h + lane < nc) {
-                    const int sl = (mhi + 64 * h + lane) & (META_POS - 1);
-                    mr_m[sl] = pm_m[h]; mr_g[sl] = pm_g[h]; mr_beta[sl] = pm_beta[h]; mr_mave[sl] = pm_mave[h]; mr_msig[sl] = pm_msig[h];
-                    if (MODE == 1) mr_nm[sl] = (uint8_t)pm_nm[h];
-                }
-            }
-        }
-        mhi += nc;
-        npm = 0;
-    };
-    auto ensure_meta = [&](int upto) {                 // slow path (uniform): meta ring must hold [.., upto)
-        if (mhi < upto) meta_commit();
-        while (mhi < upto) { meta_issue(upto); meta_commit(); }
     };
 
     // ---- the marker loop, software-pipelined over exchange generations -----------------------
@@ -1850,8 +1898,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // request the slices / sampling inputs the ring can take once the current batch has been walked to its
         // end.  Wavefronts 1-3 get here at once (they skip the block above) and issue while wavefront 0 samples;
         // the column loads wait for the totals (gate inside).
-        prefetch_issue(pos + ((cur.nb * a.pf_ahead16) >> 4) + RPOS, cur.gen + 1u);
-        meta_issue(pos + cur.nb + META_POS);
+        meta_ids(pos + cur.nb + META_POS);
+        prefetch_issue(pos + ((cur.nb * a.pf_ahead16) >> 4) + RPOS, cur.gen + 1u, true);
         PROF(2);   // prefetch issue
         if (bad) ctl[C_BAD] = 1;
         lds_barrier();                                // no vmcnt drain: prefetches stay in flight

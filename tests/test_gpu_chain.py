@@ -335,7 +335,8 @@ def test_per_step_calls_and_the_sweep_kernel_are_one_chain(gpu):
     """gmrm_sampler_begin_steps / _step / _end_steps (the reference's per-marker loop, bayes.cpp:376-492, with the
     residual update applied by the caller, bayes.cpp:681-706) interleaved with kernel sweeps on ONE shard: iteration 1
     and 3 through the persistent kernel, 2 and 4 marker by marker.  Every iteration must be the oracle's plain chain
-    bit for bit, acum included: the host restatement of the Gibbs step and the kernel are interchangeable."""
+    bit for bit (acum, the reference's per-step scratch, after the per-step iterations): the host restatement of the Gibbs step
+    and the kernel are interchangeable."""
     from oracle import orc
     case = cases.CASE_BY_NAME["ragged"]
     inp = cases.make_inputs(case)
@@ -369,7 +370,8 @@ def test_per_step_calls_and_the_sweep_kernel_are_one_chain(gpu):
             c.iterate(it)
             hy = smp.hyper(t)
             assert np.array_equal(ctx.betas(t), c.betas) and np.array_equal(ctx.comp(t), c.comp), (it, t)
-            assert np.array_equal(ctx.acum(t), c.acum), (it, t)
+            if it % 2 == 0:                                  # acum is the reference's per-marker scratch (bayes.cpp:445-474: written and
+                assert np.array_equal(ctx.acum(t), c.acum), (it, t)   # read inside one marker step); the per-step entries keep it, the sweep kernel does not
             assert np.array_equal(ctx.get_epsilon(t), c.eps), (it, t)
             assert hy.sigmae == c.sigmae and hy.mu == c.mu and np.array_equal(hy.pi_est, np.asarray(c.pi_est).reshape(-1))
             assert smp.csv_line(t, it) == c.csv_line(it)
