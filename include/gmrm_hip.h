@@ -180,7 +180,9 @@ typedef struct gmrm_sweep_out {
 int gmrm_set_groups(gmrm_ctx* ctx, const int* group_local);
 int gmrm_sweep_launch(gmrm_ctx* ctx, int t, const gmrm_sweep_in* in);   /* asynchronous */
 int gmrm_sweep_finish(gmrm_ctx* ctx, int t, gmrm_sweep_out* out);       /* waits, collects */
-/* Per-marker chain state of phenotype t (Phenotype::betas / comp / acum). */
+/* Per-marker chain state of phenotype t (Phenotype::betas / comp / acum).  acum is the reference's scratch of ONE marker
+ * step (bayes.cpp:445-474 writes and reads it inside the step, nothing reads it later): the per-step entries
+ * (gmrm_sampler_step) keep it, the sweep kernel does not store it. */
 int gmrm_get_betas(gmrm_ctx* ctx, int t, double* betas);
 int gmrm_get_comp(gmrm_ctx* ctx, int t, int* comp);
 int gmrm_get_acum(gmrm_ctx* ctx, int t, double* acum);
