@@ -640,7 +640,8 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, T
         // finite) sends the whole pass through the exact code below -- same chain, bit for bit, either way.
         bool screened = false;                                           // (uniform)
 #if GM_SCREEN
-        if (w.screen) {                                                  // (uniform; at high update rates nearly every pass holds a stop: skip the attempt)
+        if (CK == 0 && w.screen) {                                       // (uniform; at high update rates nearly every pass holds a stop: skip the attempt --
+                                                                         //  and the kernels that cross stops are launched for such sweeps only: not compiled in)
             bool sure = true;
             if (use) {
                 const double n2 = num * num;
