@@ -31,7 +31,7 @@ class SweepOut(C.Structure):
     _fields_ = [("cass", c_int_p), ("rng_state", C.c_uint32 * 624), ("rng_index", C.c_int),
                 ("n_updates", C.c_longlong), ("n_batches", C.c_longlong), ("device_ms", C.c_double),
                 ("n_planned_stops", C.c_longlong), ("n_stale_dots", C.c_longlong), ("n_fast_batches", C.c_longlong),
-                ("n_crossed_stops", C.c_longlong)]
+                ("n_crossed_stops", C.c_longlong), ("n_screen_tries", C.c_longlong), ("n_screened_passes", C.c_longlong)]
 
 
 class SamplerOpts(C.Structure):
@@ -45,7 +45,7 @@ class HyperC(C.Structure):
                 ("sigmag", C.c_double * GMAX), ("pi_est", C.c_double * (GMAX * KMAX)),
                 ("n_updates", C.c_longlong), ("n_batches", C.c_longlong), ("sweep_device_ms", C.c_double),
                 ("n_planned_stops", C.c_longlong), ("n_stale_dots", C.c_longlong), ("n_fast_batches", C.c_longlong),
-                ("n_crossed_stops", C.c_longlong)]
+                ("n_crossed_stops", C.c_longlong), ("n_screen_tries", C.c_longlong), ("n_screened_passes", C.c_longlong)]
 
 
 class GeometryC(C.Structure):

@@ -70,6 +70,8 @@ class Hyper:
     n_stale_dots: int = 0
     n_fast_batches: int = 0
     n_crossed_stops: int = 0
+    n_screen_tries: int = 0
+    n_screened_passes: int = 0
 
 
 class Context:
@@ -404,7 +406,8 @@ class Sampler:
         check(self.lib.gmrm_sampler_get(self.h, int(t), C.byref(h)))
         return Hyper(h.sigmae, h.mu, h.m0_sum, np.array(h.sigmag[:self.G]),
                      np.array(h.pi_est[:self.G * self.K]), h.n_updates, h.n_batches, h.sweep_device_ms,
-                     h.n_planned_stops, h.n_stale_dots, h.n_fast_batches, h.n_crossed_stops)
+                     h.n_planned_stops, h.n_stale_dots, h.n_fast_batches, h.n_crossed_stops,
+                     h.n_screen_tries, h.n_screened_passes)
 
     def csv_line(self, t, it) -> bytes:
         buf = C.create_string_buffer(50000)      # LENBUF, src/const.hpp:3

@@ -163,6 +163,9 @@ static int ctx_create_body(gmrm_ctx* c, int device, int N, int M, int Mt, int S,
     if (const char* e = std::getenv("GMRM_SPEC_FACTOR16")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) c->spec_factor16 = v; }
     if (const char* e = std::getenv("GMRM_CROSS_FRAC16")) { int v = std::atoi(e); if (v >= 1 && v <= 16) c->cross_frac16 = v; }
     if (const char* e = std::getenv("GMRM_CROSS_DENSITY")) { double v = std::atof(e); if (v >= 0.0 && v <= 1.0) c->cross_density = v; }
+    // the sampling screen (sweep.hip, walk_piece) is tried when the recent run length is at least this many sixteenths of a
+    // marker; 0: in every pass (tests put the screened branch under the oracle that way), 1000000: never
+    if (const char* e = std::getenv("GMRM_SCREEN_MIN_RUN16")) { int v = std::atoi(e); if (v >= 0 && v <= 1000000) c->screen_min_run16 = v; }
     if (const char* e = std::getenv("GMRM_SPIN_TIMEOUT_MS")) { int v = std::atoi(e); if (v >= 1 && v <= 60000) c->spin_timeout_ms = v; }
 
     hipError_t e = hipSuccess;
@@ -678,6 +681,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     }
     a.nb_factor16 = c->nb_factor16;
     a.spec_factor16 = c->spec_factor16;
+    a.screen_min_run16 = c->screen_min_run16;
     a.pf_ahead16 = c->pf_ahead16;
     a.miss_mode = tr.miss_mode;
     if (std::getenv("GMRM_FORCE_MIXED")) a.miss_mode = 1;     // diagnostic: run any block through the per-marker-layout kernel
@@ -739,7 +743,7 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
     if (!tr.in_flight) return fail(GMRM_ESTATE, "no sweep in flight for this phenotype");
     tr.in_flight = false;
     if (tr.empty) {
-        if (out) { out->n_updates = 0; out->n_batches = 0; out->device_ms = 0.0; out->n_planned_stops = 0; out->n_stale_dots = 0; out->n_fast_batches = 0; out->n_crossed_stops = 0;
+        if (out) { out->n_updates = 0; out->n_batches = 0; out->device_ms = 0.0; out->n_planned_stops = 0; out->n_stale_dots = 0; out->n_fast_batches = 0; out->n_crossed_stops = 0; out->n_screen_tries = 0; out->n_screened_passes = 0;
                    if (out->cass) std::memset(out->cass, 0, sizeof(int) * (size_t)tr.G * tr.K); }
         return GMRM_OK;
     }
@@ -779,7 +783,7 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
         long long st[40];
         HIPCHK(hipMemcpy(st, tr.stats, sizeof(st), hipMemcpyDeviceToHost));
         out->n_updates = st[0]; out->n_batches = st[1]; out->n_planned_stops = st[29]; out->n_stale_dots = st[30];
-        out->n_fast_batches = st[31]; out->n_crossed_stops = st[32];
+        out->n_fast_batches = st[31]; out->n_crossed_stops = st[32]; out->n_screen_tries = st[33]; out->n_screened_passes = st[34];
         if (const char* path = std::getenv("GMRM_SWEEP_TRACE")) {
             if (tr.trace) {
                 std::vector<unsigned long long> h((size_t)256 * 64 * 8);

@@ -49,6 +49,7 @@ struct SweepArgs {
     int nb_factor16;               // next batch >= nb_factor16/16 x the run-length EMA, as a power of two (default 24 = 1.5x)
     int pf_ahead16;                // the prefetch requests slices up to pos + nb * pf_ahead16 / 16 + ring: 16 assumes the batch is walked to its end
     int spec_factor16;             // speculate when EMA >= spec_factor16/16 batches (default 64 = 4x: rarely pays)
+    int screen_min_run16;          // the sampling screen is tried when the run-length EMA (1/16 marker) is at least this
     int miss_mode;                 // markers with a missing genotype among the phenotyped individuals: 0 none, 1 some, 2 all
     unsigned long long spin_ticks; // every grid-wide wait gives up after this many s_memrealtime ticks (100 MHz)
     // LDS carve of this launch (sweep.hip, carve_for: depends on G, K): byte offsets of the component counts, the per-group

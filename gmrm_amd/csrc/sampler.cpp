@@ -27,7 +27,7 @@ struct Chain {                       // class Phenotype, the host-resident part
     std::vector<int> midx, cass, m0;
     std::vector<double> sigmag, pi_est, beta_sqn, betas;
     double sigmae = 0.0, mu = 0.0, epssum = 0.0;
-    long long n_updates = 0, n_batches = 0, n_planned = 0, n_stale = 0, n_fastb = 0, n_cross = 0;
+    long long n_updates = 0, n_batches = 0, n_planned = 0, n_stale = 0, n_fastb = 0, n_cross = 0, n_scrt = 0, n_scr = 0;
     double sweep_ms = 0.0;
     bool preshuffled = false;        // midx already holds the NEXT iteration's order (shuffled while the GPU swept)
     // host copies the per-step schedule works on (gmrm_sampler_begin_steps .. _end_steps)
@@ -168,7 +168,7 @@ int gmrm_sampler_begin_parts(gmrm_sampler* s, const double* mu_use) {
         c.preshuffled = false;
         std::fill(c.m0.begin(), c.m0.end(), 0);
         std::fill(c.cass.begin(), c.cass.end(), 0);
-        c.n_updates = 0; c.n_batches = 0; c.sweep_ms = 0.0; c.n_planned = 0; c.n_stale = 0; c.n_fastb = 0; c.n_cross = 0;
+        c.n_updates = 0; c.n_batches = 0; c.sweep_ms = 0.0; c.n_planned = 0; c.n_stale = 0; c.n_fastb = 0; c.n_cross = 0; c.n_scrt = 0; c.n_scr = 0;
     }
     return GMRM_OK;
 }
@@ -216,7 +216,7 @@ static int finish_one(gmrm_sampler* s, int t) {
         c.dist_d.idx = out.rng_index;
     }
     c.n_updates += out.n_updates; c.n_batches += out.n_batches; c.sweep_ms += out.device_ms;
-    c.n_planned += out.n_planned_stops; c.n_stale += out.n_stale_dots; c.n_fastb += out.n_fast_batches; c.n_cross += out.n_crossed_stops;
+    c.n_planned += out.n_planned_stops; c.n_stale += out.n_stale_dots; c.n_fastb += out.n_fast_batches; c.n_cross += out.n_crossed_stops; c.n_scrt += out.n_screen_tries; c.n_scr += out.n_screened_passes;
     return GMRM_OK;
 }
 int gmrm_sampler_finish_part(gmrm_sampler* s) {
@@ -316,7 +316,7 @@ static int begin_steps_body(gmrm_sampler* s, const double* mu_use) {
             if (int r = gmrm_get_acum(ctx, t, c.acum.data())) return r;
             if (int r = gmrm_get_marker_stats(ctx, t, c.mave.data(), c.msig.data())) return r;
         }
-        c.n_updates = 0; c.n_batches = 0; c.n_planned = 0; c.n_stale = 0; c.n_fastb = 0; c.n_cross = 0; c.sweep_ms = 0.0;
+        c.n_updates = 0; c.n_batches = 0; c.n_planned = 0; c.n_stale = 0; c.n_fastb = 0; c.n_cross = 0; c.n_scrt = 0; c.n_scr = 0; c.sweep_ms = 0.0;
     }
     return GMRM_OK;
 }
@@ -545,7 +545,7 @@ int gmrm_sampler_get(gmrm_sampler* s, int t, gmrm_hyper* out) {
     for (int g = 0; g < s->G; g++) out->sigmag[g] = c.sigmag[g];
     for (int i = 0; i < s->G * s->K; i++) out->pi_est[i] = c.pi_est[i];
     out->n_updates = c.n_updates; out->n_batches = c.n_batches; out->sweep_device_ms = c.sweep_ms;
-    out->n_planned_stops = c.n_planned; out->n_stale_dots = c.n_stale; out->n_fast_batches = c.n_fastb; out->n_crossed_stops = c.n_cross;
+    out->n_planned_stops = c.n_planned; out->n_stale_dots = c.n_stale; out->n_fast_batches = c.n_fastb; out->n_crossed_stops = c.n_cross; out->n_screen_tries = c.n_scrt; out->n_screened_passes = c.n_scr;
     return GMRM_OK;
 }
 

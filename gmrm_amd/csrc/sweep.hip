@@ -124,7 +124,7 @@ template <int R> static Carve carve_for(int G, int K) {
 }
 template <int R> constexpr int lds_total() { return L_TOTAL; }
 
-enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD, C_TOTF, C_RANGE, C_PLN };
+enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD, C_TOTF, C_RANGE, C_PLN, C_SCRMIN, C_NSCRT, C_NSCR };
 
 size_t sweep_lds_bytes() { return (size_t)L_TOTAL; }
 
@@ -656,6 +656,7 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, T
                 sure = okd && (prob * (1.0 + 1.002 * (double)sf) <= 0.999999);
             }
             screened = __ballot(act && !sure) == 0ull;
+            if (lane == 0) { ctl[C_NSCRT]++; if (screened) ctl[C_NSCR]++; }   // (counters of the launch: plain LDS adds, nobody waits for them)
         }
 #endif
         if (!screened && use) acum_v = decide0<K>(num, tb, inv2sige, muk, logl);
@@ -769,7 +770,7 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
     Walk w;
     w.cursor = ctl[C_CURSOR]; w.run = 2 * nb; w.nupd = 0; w.ncross = 0; w.from = 0; w.ndone = nb;
     w.stopped = false; w.planned = false; w.repeek = false; w.q = -1; w.at = 0; w.ai = 0; w.bi = 0; w.xs = 0;
-    w.screen = ctl[C_EMA] >= 16 * 48;                                // recent run length (1/16 marker): a pass of 64 markers has a fair chance to hold no stop
+    w.screen = ctl[C_EMA] >= ctl[C_SCRMIN];                              // recent run length (1/16 marker): a pass of 64 markers has a fair chance to hold no stop
     walk_piece<K, CK, true>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
     if (CK != 0) {
         if (__builtin_expect(w.q >= 0, 0))                           // (uniform) the walk met a marker it may cross
@@ -1056,6 +1057,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         ctl[C_BAD] = 0;
         ctl[C_TOTF] = 0;
         ctl[C_RANGE] = 0;
+        ctl[C_SCRMIN] = a.screen_min_run16; ctl[C_NSCRT] = 0; ctl[C_NSCR] = 0;
         ctl[C_EMA] = 16 * a.batch_init / 2;
         ctl[C_NBNEXT] = a.batch_init < 16 ? 16 : (a.batch_init > BMAX ? BMAX : a.batch_init);
     }
@@ -1975,6 +1977,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             *a.rng_index = ctl[C_CURSOR];
             a.stats[0] = n_upd; a.stats[1] = n_batch; a.stats[2] = max_nb; a.stats[3] = n_disc;
             a.stats[29] = n_planned; a.stats[30] = n_stale; a.stats[31] = n_fastb; a.stats[32] = n_cross;
+            a.stats[33] = ctl[C_NSCRT]; a.stats[34] = ctl[C_NSCR];
         }
     }
 #ifdef GM_SWEEP_PROF

@@ -174,6 +174,9 @@ typedef struct gmrm_sweep_out {
                                /* free of missing genotypes among phenotyped individuals)    */
     long long n_crossed_stops; /* residual updates the walk went past inside a round (the    */
                                /* dot products behind them were patched exactly)             */
+    long long n_screen_tries;  /* passes of 64 markers in which the cheap certain bound was  */
+                               /* tried in front of the exact probabilities (sweep.hip)      */
+    long long n_screened_passes; /* ... and held for every lane: the exact code was skipped  */
 } gmrm_sweep_out;
 
 /* Per-marker group labels (Bayes::group_index restricted to [S, S+M)), shared by all t. */
@@ -236,6 +239,7 @@ typedef struct gmrm_hyper {    /* one phenotype's state after an iteration      
     long long n_updates, n_batches;
     double sweep_device_ms;
     long long n_planned_stops, n_stale_dots, n_fast_batches, n_crossed_stops;   /* see gmrm_sweep_out */
+    long long n_screen_tries, n_screened_passes;
 } gmrm_hyper;
 
 int gmrm_sampler_create(gmrm_sampler** out, gmrm_ctx* ctx, const gmrm_sampler_opts* opts);

@@ -133,7 +133,7 @@ def run_gpu(case: Case, inp, iters=None, seed=None, shuffle=True, mimic_hydra=Fa
         ctx.upload_trait(t, eps, mask4, nonas)
     stats = [ctx.compute_markers_statistics(t) for t in range(len(traits))]
     smp = gmrm_amd.Sampler(ctx, seed, inp["cva"], inp["group_index"], shuffle=shuffle, mimic_hydra=mimic_hydra)
-    hist = [dict(comp=[], betas=[], sigmae=[], sigmag=[], pi=[], mu=[], m0=[], csv=[], eps=None, nupd=[], nbatch=[], ncross=[])
+    hist = [dict(comp=[], betas=[], sigmae=[], sigmag=[], pi=[], mu=[], m0=[], csv=[], eps=None, nupd=[], nbatch=[], ncross=[], nscrt=[], nscr=[])
             for _ in traits]
     for it in range(1, iters + 1):
         if parts:
@@ -147,6 +147,7 @@ def run_gpu(case: Case, inp, iters=None, seed=None, shuffle=True, mimic_hydra=Fa
             h["sigmae"].append(hy.sigmae); h["sigmag"].append(hy.sigmag); h["pi"].append(hy.pi_est)
             h["mu"].append(hy.mu); h["m0"].append(hy.m0_sum); h["csv"].append(smp.csv_line(t, it))
             h["nupd"].append(hy.n_updates); h["nbatch"].append(hy.n_batches); h["ncross"].append(hy.n_crossed_stops)
+            h["nscrt"].append(hy.n_screen_tries); h["nscr"].append(hy.n_screened_passes)
     for t in range(len(traits)):
         hist[t]["eps"] = ctx.get_epsilon(t)
         hist[t]["mave"], hist[t]["msig"] = stats[t]

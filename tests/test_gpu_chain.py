@@ -33,6 +33,59 @@ def test_chain_matches_oracle_and_golden(gpu, name):
         assert sum(h["ncross"]) > 0 and h["nbatch"][-1] < h["nupd"][-1], (h["ncross"], h["nbatch"], h["nupd"])
 
 
+def _null_case(N=20_000, M=6_000, iters=4, seed=11):
+    """A phenotype without signal (y ~ N(0,1), what bench.py's headline workload uses): after the first sweeps well under
+    1 % of the visits change an effect, runs exceed 64 markers and whole passes of the sampling wavefront are decided by
+    the screen (sweep.hip, walk_piece) instead of the exact probabilities."""
+    case = cases.Case("null", N, M, 1, 4, 1, 0.0, 60, seed, iters, 5)
+    inp = cases.make_inputs(case)
+    inp["y"][0] = np.random.default_rng(seed).normal(size=N)
+    return case, inp
+
+
+@pytest.mark.parametrize("name", [c.name for c in cases.CASES] + ["geo_fast", "geo_general", "null"])
+def test_screened_sampling_path_is_the_oracle_chain(gpu, monkeypatch, name):
+    """the branch that produces the headline number.  GMRM_SCREEN_MIN_RUN16=0 tries the cheap certain
+    bound in front of the exact probabilities in EVERY pass of 64 markers (default: only when the recent run length is
+    >= 48 markers), GMRM_NO_CROSS=1 keeps the launch on the kernels the screen is compiled into (the continuation
+    kernels of the dense sweeps have none).  The chain must be the oracle's bit for bit -- components, effects, residual,
+    hyper-parameters, .csv bytes -- with passes that the screen decided (n_screened_passes > 0 where runs are long) AND
+    passes in which an uncertain lane sent everybody through the exact code (tries > screened)."""
+    monkeypatch.setenv("GMRM_SCREEN_MIN_RUN16", "0")
+    monkeypatch.setenv("GMRM_NO_CROSS", "1")
+    if name == "null":
+        case, inp = _null_case()
+    elif name == "geo_fast":
+        case = cases.Case("geo_fast", 50_000, 900, 1, 4, 1, 0.0, 300, 171014, 3, 20); inp = cases.make_inputs(case)
+    elif name == "geo_general":
+        case = cases.Case("geo_general", 20_003, 700, 3, 4, 1, 0.05, 200, 7, 3, 20); inp = cases.make_inputs(case)
+    else:
+        case = cases.CASE_BY_NAME[name]; inp = cases.make_inputs(case)
+    got = cases.run_gpu(case, inp)
+    want = cases.run_oracle(case, inp, canon=True)
+    cases.assert_same_history(got, want, exact=True)
+    for h in got:
+        assert h["ncross"][-1] == 0                                     # (the kernels without continuation ran)
+        assert h["nscrt"][-1] > 0, "the screen was never tried"
+        assert h["nscrt"][-1] > h["nscr"][-1], "no pass fell back to the exact probabilities"
+    if name == "null":
+        h = got[0]
+        assert h["nscr"][-1] > 10, (h["nscr"], h["nscrt"])               # whole passes decided by the bound (counters are per sweep)
+        assert h["nupd"][-1] < 0.03 * case.M, h["nupd"]                  # the low-update regime
+        ref = cases.run_oracle(case, inp, canon=False)                   # north_star bar against the reference-order arithmetic
+        cases.assert_same_history(got, ref, exact=False, rtol=1e-6)
+
+
+def test_screen_is_taken_by_default_where_runs_are_long(gpu):
+    """The same null-phenotype chain with the library's default knobs: the run-length estimate switches the screen on by
+    itself in the stationary sweeps (what bench.py measures), and the chain is still the oracle's."""
+    case, inp = _null_case(iters=5)
+    got = cases.run_gpu(case, inp)
+    want = cases.run_oracle(case, inp, canon=True)
+    cases.assert_same_history(got, want, exact=True)
+    assert got[0]["nscr"][-1] > 0 and got[0]["nscrt"][-1] >= got[0]["nscr"][-1], (got[0]["nscr"], got[0]["nscrt"])
+
+
 @pytest.mark.parametrize("name,k", [("small", 1), ("small", 37), ("ragged", 64), ("groups", 200), ("groups", 512)])
 def test_sweep_in_parts_is_the_same_chain(gpu, name, k):
     """gmrm_sampler_begin_parts / _launch_part / _finish_part (the building block of `--sync-every k`): one shard that cuts
@@ -222,14 +275,20 @@ def test_missing_genotypes_and_24_groups_full_width(gpu):
     gi = (np.arange(M) % G).astype(np.int32)
     smp = gmrm_amd.Sampler(ctx, 77, cva, gi)
     ch = orc.Chain(N, bed, eps, mask4, nonas, gi, cva, 77, canon=True)
+    ref = orc.Chain(N, bed, eps, mask4, nonas, gi, cva, 77, canon=False)      # the reference's own summation order
     for it in (1, 2):
         smp.iterate(it)
         ch.iterate(it)
+        ref.iterate(it)
         assert np.array_equal(ctx.comp(0), ch.comp)
         assert np.array_equal(ctx.betas(0), ch.betas) and np.all(np.isfinite(ch.betas))
         hy = smp.hyper(0)
         assert hy.sigmae == ch.sigmae and np.array_equal(hy.sigmag, ch.sigmag)
+        # north_star bar at BASELINE width: identical inclusion indices, effects within 1e-6 relative
+        assert np.array_equal(ctx.comp(0), ref.comp), f"reference-order oracle picks other components in sweep {it}"
+        np.testing.assert_allclose(ctx.betas(0), ref.betas, rtol=1e-6, atol=1e-300)
     assert np.array_equal(ctx.get_epsilon(0), ch.eps)
+    np.testing.assert_allclose(ctx.get_epsilon(0), ref.eps, rtol=0, atol=1e-9)
     assert (ctx.betas(0) != 0).sum() > 0
     smp.close(); ctx.close()
 

@@ -114,6 +114,7 @@ def test_c4_four_traits_at_full_width_run_as_queued_pairs(gpu):
     geo = ctx.geometry()
     assert geo["conc"] == 2 and geo["R"] == 4, geo        # the queued-pairs path, not four at once
     chains = [orc.Chain(N, bed, e, m4, na, gi, cva, 171014, canon=True) for (e, m4, na) in traits]
+    refs = [orc.Chain(N, bed, e, m4, na, gi, cva, 171014, canon=False) for (e, m4, na) in traits]   # the reference's summation order
     for it in (1, 2):
         smp.iterate(it)
         for t, ch in enumerate(chains):
@@ -122,6 +123,9 @@ def test_c4_four_traits_at_full_width_run_as_queued_pairs(gpu):
             assert np.array_equal(ctx.betas(t), ch.betas)
             hy = smp.hyper(t)
             assert hy.sigmae == ch.sigmae and np.array_equal(hy.sigmag, ch.sigmag)
+            refs[t].iterate(it)                              # north_star bar at N = 500 000: same indices, effects within 1e-6
+            assert np.array_equal(ctx.comp(t), refs[t].comp), f"trait {t} iteration {it}: reference-order oracle differs"
+            np.testing.assert_allclose(ctx.betas(t), refs[t].betas, rtol=1e-6, atol=1e-300)
     for t, ch in enumerate(chains):
         assert np.array_equal(ctx.get_epsilon(t), ch.eps)
     assert len({c.betas.tobytes() for c in chains}) == T   # four different chains
@@ -129,22 +133,29 @@ def test_c4_four_traits_at_full_width_run_as_queued_pairs(gpu):
     ctx.close()
 
 
-@pytest.mark.parametrize("name,na_rate,miss_rate,G,dirty", [("c3", 0.002, 0.0, 1, 0.0), ("c5", 0.05, 0.05, 24, 0.0),
-                                                           ("mixed", 0.0, 0.001, 1, 0.005)])
-def test_full_size_chain_keeps_its_invariant(gpu, name, na_rate, miss_rate, G, dirty):
+@pytest.mark.parametrize("name,N,M,T,na_rate,miss_rate,G,dirty",
+                         [("c2", 50_000, 100_000, 1, 0.002, 0.0, 1, 0.0),
+                          ("c3", 500_000, 1_000_000, 1, 0.002, 0.0, 1, 0.0),
+                          ("c4", 500_000, 1_000_000, 4, 0.002, 0.0, 1, 0.0),
+                          ("c5", 500_000, 1_000_000, 1, 0.05, 0.05, 24, 0.0),
+                          ("mixed", 500_000, 1_000_000, 1, 0.0, 0.001, 1, 0.005)])
+def test_full_size_chain_keeps_its_invariant(gpu, name, N, M, T, na_rate, miss_rate, G, dirty):
     """BASELINE configs 3 and 5 (5 % NAs, 5 % missing genotypes, 24 groups: the 4-value exchange layout), and a block
     with missing calls in 0.5 % of the markers only (the per-marker layout with its sparse missing-genotype terms), at FULL size (500 000 individuals x 1 000 000 markers, device-generated genotypes, 125 GB):
     no oracle can sweep this in test time, so the chain is held to the property that defines it.  After k sweeps the
     residual must be  y_std - mu - sum_m beta_m z_m  for the effects the sweeps left behind, with z the standardised
     genotype columns: recomputed here from the kernel's own outputs with gmrm_predict_g (an independent kernel that
     adds the markers in order).  Every residual update of three sweeps (~140 000 columns of 125 KB) has to be right
-    for this to hold to 1e-9; the bookkeeping (component counts, markers in the model, batches) is checked beside it."""
-    N, M = 500_000, 1_000_000
+    for this to hold to 1e-9; the bookkeeping (component counts, markers in the model, batches) is checked beside it.
+    c2 (50 000 x 100 000) and c4 (four phenotypes over the 1M-marker block, two queued pairs at R = 4) are BASELINE's other
+    two configurations at their own full sizes."""
     rng = np.random.default_rng(2)
-    y = rng.normal(size=N)
-    isna = (rng.random(N) < na_rate).astype(np.uint8)
-    eps0, mask4, nonas = orc.phen_prepare(y, isna)
-    ctx = gmrm_amd.Context(N, M)
+    traits = []
+    for t in range(T):
+        y = rng.normal(size=N)
+        isna = (rng.random(N) < na_rate).astype(np.uint8)
+        traits.append(orc.phen_prepare(y, isna))
+    ctx = gmrm_amd.Context(N, M, T=T)
     try:
         ctx.synth_bed(171014, 0.4, 0.0 if dirty else miss_rate)
         if dirty:                                                    # code 01 (missing) in `miss_rate` of the calls of a few markers
@@ -156,31 +167,38 @@ def test_full_size_chain_keeps_its_invariant(gpu, name, na_rate, miss_rate, G, d
             cols[rows, byte] = (cols[rows, byte] & ~(np.uint8(3) << sh)) | (np.uint8(1) << sh)
             ctx.upload_bed(cols, 0)
             del cols, who, rows, byte, sh
-        ctx.upload_trait(0, eps0, mask4, nonas)
-        ctx.compute_markers_statistics(0)
+        for t, (eps0, mask4, nonas) in enumerate(traits):
+            ctx.upload_trait(t, eps0, mask4, nonas)
+            ctx.compute_markers_statistics(t)
         cva = np.tile(np.array([[0.0, 0.0001, 0.001, 0.01]]), (G, 1)) * np.linspace(1.0, 2.0, G)[:, None]
         smp = gmrm_amd.Sampler(ctx, 171014, cva, rng.integers(0, G, M).astype(np.int32))
-        keep = np.repeat(mask4, 4) >> np.tile(np.arange(4), len(mask4)) & 1        # 1 = phenotype present
+        if name == "c4":
+            geo = ctx.geometry()
+            assert geo["conc"] == 2 and geo["R"] == 4, geo                         # the queued-pairs path
         total_updates = 0
         for it in (1, 2, 3):
             smp.iterate(it)
-            hy = smp.hyper(0)
-            total_updates += hy.n_updates
-            comp, betas = ctx.comp(0), ctx.betas(0)
-            counts = np.bincount(comp, minlength=4)
-            assert counts.sum() == M and int((betas != 0.0).sum()) == M - counts[0] == hy.m0_sum, name
-            # a round ends at a residual update unless the walk crosses it (markers that were in the model, fast layout only)
-            assert hy.n_batches >= hy.n_updates - hy.n_crossed_stops and 0.1 < hy.sigmae < 2.0
-            if name == "c3" and it >= 2:
-                assert hy.n_crossed_stops > 0                                    # sweeps 2, 3: ~8 % of the markers in the model
-            if dirty:
-                assert 0 < hy.n_fast_batches < hy.n_batches                      # clean and mixed batches both occur
-            g = ctx.predict_g(0, betas)
-            want = (eps0[:N] - hy.mu - g) * keep[:N]
-            got = ctx.get_epsilon(0)[:N]
-            assert np.max(np.abs(got - want)) < 1e-9, (it, float(np.max(np.abs(got - want))))
-            assert not got[keep[:N] == 0].any()                                    # NA individuals stay out of the residual
-        assert total_updates > 100_000
+            for t, (eps0, mask4, nonas) in enumerate(traits):
+                keep = np.repeat(mask4, 4) >> np.tile(np.arange(4), len(mask4)) & 1        # 1 = phenotype present
+                hy = smp.hyper(t)
+                total_updates += hy.n_updates
+                comp, betas = ctx.comp(t), ctx.betas(t)
+                counts = np.bincount(comp, minlength=4)
+                assert counts.sum() == M and int((betas != 0.0).sum()) == M - counts[0] == hy.m0_sum, name
+                # a round ends at a residual update unless the walk crosses it (markers that were in the model)
+                assert hy.n_batches >= hy.n_updates - hy.n_crossed_stops and 0.1 < hy.sigmae < 2.0
+                if name == "c3" and it >= 2:
+                    assert hy.n_crossed_stops > 0                                    # sweeps 2, 3: ~8 % of the markers in the model
+                if dirty:
+                    assert 0 < hy.n_fast_batches < hy.n_batches                      # clean and mixed batches both occur
+                g = ctx.predict_g(t, betas)
+                want = (eps0[:N] - hy.mu - g) * keep[:N]
+                got = ctx.get_epsilon(t)[:N]
+                assert np.max(np.abs(got - want)) < 1e-9, (it, t, float(np.max(np.abs(got - want))))
+                assert not got[keep[:N] == 0].any()                                    # NA individuals stay out of the residual
+        assert total_updates > (100_000 if M == 1_000_000 else 10_000) * T
+        if T > 1:
+            assert len({ctx.betas(t).tobytes() for t in range(T)}) == T               # different phenotypes, different chains
         smp.close()
     finally:
         ctx.close()
