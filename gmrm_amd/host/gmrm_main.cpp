@@ -354,8 +354,23 @@ int main(int argc, char** argv) {
         read_mixtures(opt.group_mixture_file, cva, G, K);
     }
 
+    // Limits of this build, said out loud (the reference accepts any number of groups and mixtures, options.cpp:222-286, and
+    // any N, phenotype.cpp:22): the sampling step keeps the per-group tables in LDS and spreads a marker's component search
+    // over one wavefront; the sweep kernel keeps the whole residual on chip, one slice of individuals per compute unit.
+    if (!opt.predict && K > GMRM_KMAX)
+        fatal("FATAL  : " + std::to_string(K) + " mixture components per group in " + opt.group_mixture_file + ": this build supports at most "
+              + std::to_string(GMRM_KMAX) + " (limit of the GPU sampling step; upstream gmrm has none).");
+    if (!opt.predict && K < 2)
+        fatal("FATAL  : a group mixture needs at least 2 components (0.0 and one variance); found " + std::to_string(K) + ".");
+    if (!opt.predict && G > 64)
+        fatal("FATAL  : " + std::to_string(G) + " groups in " + opt.group_mixture_file + ": this build supports at most 64 "
+              "(limit of the GPU sampling step's on-chip tables; upstream gmrm has none).");
+    if (N > 1048576)
+        fatal("FATAL  : " + std::to_string(N) + " individuals: this build supports at most 1048576 (256 compute units x 256 threads x 16 "
+              "individuals: the residual stays on chip during a sweep; upstream gmrm has no limit).");
     if (gmrm_device_count() < 1) fatal("FATAL  : no HIP device visible; this build has no CPU path.");
     const int T = (int)opt.phen_files.size();
+    if (T > 64) fatal("FATAL  : " + std::to_string(T) + " phenotype files: this build supports at most 64 per run.");
     // Marker shards, one per GPU, by the reference's block rule (Bayes::set_block_of_markers,
     // bayes.cpp:903-925): what MPI ranks are upstream.  `ctx` / `smp` below are shard 0.
     std::vector<int> devs = opt.devices.empty() ? std::vector<int>{opt.device} : opt.devices;
