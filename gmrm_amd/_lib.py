@@ -1,6 +1,8 @@
 """ctypes loader for libgmrm_hip.so (C ABI: include/gmrm_hip.h)."""
 import ctypes as C
 import os
+import sys
+import warnings
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
@@ -49,7 +51,8 @@ class HyperC(C.Structure):
 
 
 class GeometryC(C.Structure):
-    _fields_ = [("R", C.c_int), ("W", C.c_int), ("conc", C.c_int), ("num_cu", C.c_int), ("max_resident_wg", C.c_int)]
+    _fields_ = [("R", C.c_int), ("W", C.c_int), ("conc", C.c_int), ("num_cu", C.c_int), ("max_resident_wg", C.c_int),
+                ("hw_queues", C.c_int)]
 
 
 class IngestStatsC(C.Structure):
@@ -164,7 +167,17 @@ def load_library():
     path = library_path()
     # eight hardware queues, so that four persistent sweeps on four streams run side by side (capi.cpp, want_hw_queues);
     # set here as well because torch may initialise the HIP runtime before libgmrm_hip.so is loaded
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    if "GPU_MAX_HW_QUEUES" not in os.environ:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        torch = sys.modules.get("torch")
+        try:
+            late = torch is not None and torch.cuda.is_initialized()
+        except Exception:
+            late = False
+        if late:                          # the runtime read its environment when torch initialised it: the default (4 queues) holds
+            warnings.warn("gmrm_amd was loaded after torch had initialised the HIP runtime: GPU_MAX_HW_QUEUES=8 comes too late, "
+                          "more than three phenotype chains will not all sweep side by side; import gmrm_amd (or set the "
+                          "variable) before the first torch.cuda call", RuntimeWarning, stacklevel=2)
     _share_torch_hip_runtime()
     if not path.exists():
         raise ImportError(f"{path} is missing: build it with `python -m gmrm_amd.build` "

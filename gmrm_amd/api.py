@@ -100,7 +100,7 @@ class Context:
         """Launch geometry of the persistent sweep kernel (R bytes per thread, W workgroups, conc chains side by side)."""
         g = _lib.GeometryC()
         check(self.lib.gmrm_ctx_geometry(self.h, C.byref(g)))
-        return dict(R=g.R, W=g.W, conc=g.conc, num_cu=g.num_cu, max_resident_wg=g.max_resident_wg)
+        return dict(R=g.R, W=g.W, conc=g.conc, num_cu=g.num_cu, max_resident_wg=g.max_resident_wg, hw_queues=g.hw_queues)
 
     def upload_bed(self, cols, first=0):
         cols = np.ascontiguousarray(cols, dtype=np.uint8)

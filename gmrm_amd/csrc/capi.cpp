@@ -9,8 +9,11 @@
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +29,8 @@ namespace gm {
 // hardware queue until it ends.  The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of
 // them shared with the null stream): with four chains the fourth queued behind the third (kernel trace: three sweeps
 // together, then one).  Ask for eight before the runtime initialises, unless the user has set it.
+// (It has no effect when the HIP runtime was initialised before this library was loaded: gmrm_ctx_geometry reports the
+// value the environment holds, and the Python loader warns when torch had initialised HIP first.)
 __attribute__((constructor)) static void want_hw_queues() { ::setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 static thread_local std::string g_err;
@@ -34,6 +39,27 @@ static int hip_fail(hipError_t e, const char* what) {
     return fail(GMRM_EHIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hip_fail(e_, #x); } while (0)
+
+// Tuning / diagnostic knobs from the environment: a value outside the accepted range is reported (once per name and
+// process) instead of being dropped silently.
+static bool env_int(const char* name, int lo, int hi, int* dst) {
+    const char* e = std::getenv(name);
+    if (!e) return false;
+    char* end = nullptr;
+    const long v = std::strtol(e, &end, 10);
+    if (end == e || *end != '\0' || v < lo || v > hi) {
+        static std::mutex mu;
+        static std::map<std::string, bool> said;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!said[name]) {
+            std::fprintf(stderr, "WARNING: libgmrm_hip: %s=%s ignored (expected an integer in [%d, %d])\n", name, e, lo, hi);
+            said[name] = true;
+        }
+        return false;
+    }
+    *dst = (int)v;
+    return true;
+}
 
 template <class T> static hipError_t dalloc(T** p, size_t n) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T));
@@ -61,29 +87,68 @@ static int device_inflight_wgs(int device, const gmrm_ctx* c, int own_extra) {
 }
 
 // The bookkeeping above is per PROCESS.  Two processes that sweep on one device cannot see each other's grids; if the
-// two could not be co-resident (each needs more than half of the device's resident workgroups) their workgroups would
-// interleave and both sweeps would end in the spin timeout.  Such sweeps therefore hold an advisory lock on a per-device
-// file from launch to finish (flock: released by the kernel if the process dies), so that they alternate instead.  One
-// descriptor per device and process, counted: contexts of one process share it (they are ordered by the bookkeeping above).
-struct DevLock { int fd = -1; int holders = 0; };
-static std::map<int, DevLock> g_dev_lock;                     // guarded by g_dev_mu
+// two could not be co-resident their workgroups would interleave and both sweeps would end in the spin timeout.  Every
+// sweep therefore holds an advisory lock on a per-device file from launch to finish (flock: released by the kernel if
+// the process dies): EXCLUSIVE when it needs more than half of the device's resident workgroups, SHARED otherwise -- a
+// small sweep waits for another process's large one and the other way round; two small ones of different processes run
+// side by side.  (Three or more processes whose small sweeps together exceed the device are NOT caught: the lock knows
+// two sizes, not a count.)  One descriptor per device and process, counted: contexts of one process share it (they are
+// ordered by the bookkeeping above) and the process holds the stronger of the modes its sweeps asked for.
+// The wait is bounded (GMRM_DEVICE_LOCK_TIMEOUT_MS, default 10 minutes) and happens BEFORE g_dev_mu is taken, so that a
+// process waiting for one device does not stop its own launches on another; a host that sweeps on several devices takes
+// them in ascending device order (shard_group.cpp), so two such hosts cannot wait for each other crosswise.
+struct DevLock { int fd = -1; int holders = 0; bool ex = false; bool warned = false; std::mutex mu; std::string path; };
+static std::mutex g_lock_map_mu;
+static std::map<int, DevLock> g_dev_lock;                     // nodes are stable; each guarded by its own mu
 
-static void devlock_acquire(int device) {                     // g_dev_mu held
-    DevLock& L = g_dev_lock[device];
-    if (L.holders++ > 0) return;
-    if (L.fd < 0) {
+static int devlock_acquire(int device, bool want_ex) {        // g_dev_mu NOT held
+    DevLock* L;
+    { std::lock_guard<std::mutex> lk(g_lock_map_mu); L = &g_dev_lock[device]; }
+    std::lock_guard<std::mutex> lk(L->mu);
+    if (L->fd < 0) {
         char bus[64] = "unknown";
         (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device);
         for (char* p = bus; *p; p++) if (*p == ':' || *p == '.' || *p == '/') *p = '_';
         const char* dir = std::getenv("GMRM_LOCK_DIR");
-        const std::string path = std::string(dir ? dir : "/tmp") + "/gmrm_hip_" + bus + ".lock";
-        L.fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        L->path = std::string(dir ? dir : "/tmp") + "/gmrm_hip_" + bus + ".lock";
+        // read-only is enough for flock, so a file another user created can be shared; never follow a link planted there
+        L->fd = ::open(L->path.c_str(), O_CREAT | O_RDONLY | O_CLOEXEC | O_NOFOLLOW, 0666);
+        if (L->fd >= 0) (void)::fchmod(L->fd, 0666);          // (fails unless we own it: then its owner has done so)
     }
-    if (L.fd >= 0) (void)::flock(L.fd, LOCK_EX);              // may wait for another process's sweep; no lock file, no guard
+    if (L->fd < 0) {                                          // no lock file, no guard across processes: say so once
+        if (!L->warned) {
+            std::fprintf(stderr, "WARNING: libgmrm_hip: cannot open the device lock file %s (%s); sweeps of OTHER processes on this device are not "
+                                 "kept apart (set GMRM_LOCK_DIR to a directory every user can write).\n", L->path.c_str(), std::strerror(errno));
+            L->warned = true;
+        }
+        L->holders++;
+        return GMRM_OK;
+    }
+    if (L->holders > 0 && (L->ex || !want_ex)) { L->holders++; return GMRM_OK; }     // held in a mode that covers this sweep
+    int limit_ms = 600000;
+    if (const char* e = std::getenv("GMRM_DEVICE_LOCK_TIMEOUT_MS")) { const int v = std::atoi(e); if (v >= 1) limit_ms = v; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        if (::flock(L->fd, (want_ex ? LOCK_EX : LOCK_SH) | LOCK_NB) == 0) break;
+        if (errno != EWOULDBLOCK && errno != EINTR)
+            return fail(GMRM_ESTATE, std::string("flock(") + L->path + "): " + std::strerror(errno));
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(limit_ms))
+            return fail(GMRM_ESTATE, "device " + std::to_string(device) + " is held by another process's sweep for more than " +
+                                     std::to_string(limit_ms) + " ms (lock file " + L->path + ", GMRM_DEVICE_LOCK_TIMEOUT_MS)");
+        ::usleep(200);
+    }
+    L->ex = L->ex || want_ex;
+    L->holders++;
+    return GMRM_OK;
 }
-static void devlock_release(int device) {                     // g_dev_mu held
-    DevLock& L = g_dev_lock[device];
-    if (L.holders > 0 && --L.holders == 0 && L.fd >= 0) (void)::flock(L.fd, LOCK_UN);
+static void devlock_release(int device) {
+    DevLock* L;
+    { std::lock_guard<std::mutex> lk(g_lock_map_mu); L = &g_dev_lock[device]; }
+    std::lock_guard<std::mutex> lk(L->mu);
+    if (L->holders > 0 && --L->holders == 0) {
+        if (L->fd >= 0) (void)::flock(L->fd, LOCK_UN);
+        L->ex = false;
+    }
 }
 
 int ctx_check_t(const gmrm_ctx* c, int t) {
@@ -117,7 +182,11 @@ static int ctx_create_body(gmrm_ctx* c, int device, int N, int M, int Mt, int S,
     // XCD, another L2) fetched as well (GMRM_STRIDE_ALIGN=16 restores that for A/B runs)
     {
         size_t al = 128;
-        if (const char* e = std::getenv("GMRM_STRIDE_ALIGN")) { const int v = std::atoi(e); if (v == 16 || v == 64 || v == 128 || v == 256) al = (size_t)v; }
+        int v = 0;
+        if (env_int("GMRM_STRIDE_ALIGN", 16, 256, &v)) {
+            if (v == 16 || v == 64 || v == 128 || v == 256) al = (size_t)v;
+            else std::fprintf(stderr, "WARNING: libgmrm_hip: GMRM_STRIDE_ALIGN=%d ignored (16, 64, 128 or 256)\n", v);
+        }
         c->stride = (c->mbytes + al - 1) / al * al;
     }
     c->num_cu = prop.multiProcessorCount;
@@ -158,15 +227,19 @@ static int ctx_create_body(gmrm_ctx* c, int device, int N, int M, int Mt, int S,
                                      std::to_string(c->conc) + " chains > " + std::to_string(c->max_resident_wg) +
                                      " resident workgroups (occupancy query x compute units)");
     }
-    if (const char* e = std::getenv("GMRM_NB_FACTOR16")) { int v = std::atoi(e); if (v >= 8 && v <= 256) c->nb_factor16 = v; }
-    if (const char* e = std::getenv("GMRM_PF_AHEAD16")) { int v = std::atoi(e); if (v >= 0 && v <= 16) c->pf_ahead16 = v; }
-    if (const char* e = std::getenv("GMRM_SPEC_FACTOR16")) { int v = std::atoi(e); if (v >= 1 && v <= 4096) c->spec_factor16 = v; }
-    if (const char* e = std::getenv("GMRM_CROSS_FRAC16")) { int v = std::atoi(e); if (v >= 1 && v <= 16) c->cross_frac16 = v; }
-    if (const char* e = std::getenv("GMRM_CROSS_DENSITY")) { double v = std::atof(e); if (v >= 0.0 && v <= 1.0) c->cross_density = v; }
+    env_int("GMRM_NB_FACTOR16", 8, 256, &c->nb_factor16);
+    env_int("GMRM_PF_AHEAD16", 0, 16, &c->pf_ahead16);
+    env_int("GMRM_SPEC_FACTOR16", 1, 4096, &c->spec_factor16);
+    env_int("GMRM_CROSS_FRAC16", 1, 16, &c->cross_frac16);
+    if (const char* e = std::getenv("GMRM_CROSS_DENSITY")) {
+        const double v = std::atof(e);
+        if (v >= 0.0 && v <= 1.0) c->cross_density = v;
+        else std::fprintf(stderr, "WARNING: libgmrm_hip: GMRM_CROSS_DENSITY=%s ignored (expected a fraction in [0, 1])\n", e);
+    }
     // the sampling screen (sweep.hip, walk_piece) is tried when the recent run length is at least this many sixteenths of a
     // marker; 0: in every pass (tests put the screened branch under the oracle that way), 1000000: never
-    if (const char* e = std::getenv("GMRM_SCREEN_MIN_RUN16")) { int v = std::atoi(e); if (v >= 0 && v <= 1000000) c->screen_min_run16 = v; }
-    if (const char* e = std::getenv("GMRM_SPIN_TIMEOUT_MS")) { int v = std::atoi(e); if (v >= 1 && v <= 60000) c->spin_timeout_ms = v; }
+    env_int("GMRM_SCREEN_MIN_RUN16", 0, 1000000, &c->screen_min_run16);
+    env_int("GMRM_SPIN_TIMEOUT_MS", 1, 60000, &c->spin_timeout_ms);
 
     hipError_t e = hipSuccess;
     const size_t bedbytes = (size_t)(M > 0 ? M : 1) * c->stride;
@@ -236,6 +309,8 @@ int gmrm_ctx_create(gmrm_ctx** out, int device, int N, int M, int Mt, int S, int
 int gmrm_ctx_geometry(const gmrm_ctx* c, gmrm_geometry* out) {
     if (!c || !out) return fail(GMRM_EINVAL, "null argument");
     out->R = c->R; out->W = c->W; out->conc = c->conc; out->num_cu = c->num_cu; out->max_resident_wg = c->max_resident_wg;
+    out->hw_queues = 0;
+    if (const char* e = std::getenv("GPU_MAX_HW_QUEUES")) out->hw_queues = std::atoi(e);
     return GMRM_OK;
 }
 
@@ -246,9 +321,9 @@ int gmrm_ctx_destroy(gmrm_ctx* c) {
         std::lock_guard<std::mutex> lk(g_dev_mu);
         auto& v = g_dev_inflight[c->device];
         v.erase(std::remove_if(v.begin(), v.end(), [&](const InFlight& f) { return f.ctx == c; }), v.end());
-        for (auto& tr : c->tr)
-            if (tr.holds_devlock) { devlock_release(c->device); tr.holds_devlock = false; }
     }
+    for (auto& tr : c->tr)
+        if (tr.holds_devlock) { devlock_release(c->device); tr.holds_devlock = false; }
     for (auto& tr : c->tr) {
         if (tr.stream) hipStreamSynchronize(tr.stream);
         hipFree(tr.eps); hipFree(tr.eps_start); hipFree(tr.namask2); hipFree(tr.mave); hipFree(tr.msig); hipFree(tr.nomiss);
@@ -618,10 +693,10 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
         return fail(GMRM_ESTATE, "parts of a sweep must be launched in order of position (expected first = " + std::to_string(tr.part_next) + ")");
     HIPCHK(hipSetDevice(c->device));
     tr.G = G; tr.K = K;
-    if (c->M == 0) { tr.in_flight = true; tr.empty = true; return GMRM_OK; }
+    if (c->M == 0) { tr.in_flight = true; tr.empty = true; tr.part_last = true; tr.part_next = 0; return GMRM_OK; }
     tr.empty = false;
-    tr.part_last = first + count == c->M;
-    tr.part_next = tr.part_last ? 0 : first + count;
+    const bool part_last = first + count == c->M;      // (the bookkeeping of a sweep in parts moves once the launch is enqueued: a
+    const int part_next = part_last ? 0 : first + count;   //  part whose uploads or launch fail can be launched again)
 
     // per-group tables of the Gibbs step, evaluated exactly as bayes.cpp:403-432 writes them
     std::vector<double> tab((size_t)G * (1 + 3 * K), 0.0);
@@ -709,6 +784,10 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     if (const char* e = std::getenv("GMRM_FAULT_DROP_WG")) {                 // test hook: launch one workgroup short, so the
         if (std::atoi(e) > 0 && grid > 1) grid -= 1;                         // grid-wide wait can never complete (timeout path)
     }
+    // another PROCESS on this device: see devlock_acquire (may wait, bounded; before the mutex)
+    const bool guarded = !std::getenv("GMRM_NO_DEVICE_LOCK");
+    if (guarded)
+        if (int r = devlock_acquire(c->device, 2 * c->W * c->conc > c->max_resident_wg)) return r;
     {
         std::unique_lock<std::mutex> lk(g_dev_mu);
         auto& v = g_dev_inflight[c->device];
@@ -717,21 +796,22 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
             if (it == v.end()) break;                   // only this context's own launches: they queue on its streams
             const hipStream_t other = it->stream;
             v.erase(it);                                // its owner's gmrm_sweep_finish still synchronises the stream
-            HIPCHK(hipStreamSynchronize(other));        // (the kernel it waits for needs nothing from this host thread)
+            const hipError_t se = hipStreamSynchronize(other);   // (the kernel it waits for needs nothing from this host thread)
+            if (se != hipSuccess) { lk.unlock(); if (guarded) devlock_release(c->device); return hip_fail(se, "hipStreamSynchronize(other sweep)"); }
         }
-        // another PROCESS on this device: see devlock_acquire
-        const bool exclusive = 2 * c->W * c->conc > c->max_resident_wg && !std::getenv("GMRM_NO_DEVICE_LOCK");
-        if (exclusive) devlock_acquire(c->device);
         hipError_t le = hipEventRecord(tr.ev0, st);
         if (le == hipSuccess) le = launch_sweep(a, c->R, st, grid);
         if (le == hipSuccess) le = hipEventRecord(tr.ev1, st);
         if (le != hipSuccess) {
-            if (exclusive) devlock_release(c->device);
+            lk.unlock();
+            if (guarded) devlock_release(c->device);
             return hip_fail(le, "sweep launch");
         }
-        tr.holds_devlock = exclusive;
+        tr.holds_devlock = guarded;
         v.push_back(InFlight{c, t, st, c->W});
     }
+    tr.part_last = part_last;
+    tr.part_next = part_next;
     tr.launch_stream = st;
     tr.in_flight = true;
     return GMRM_OK;
@@ -754,8 +834,8 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
         auto& v = g_dev_inflight[c->device];
         auto it = std::find_if(v.begin(), v.end(), [&](const InFlight& f) { return f.ctx == c && f.t == t; });
         if (it != v.end()) v.erase(it);
-        if (tr.holds_devlock) { devlock_release(c->device); tr.holds_devlock = false; }
     }
+    if (tr.holds_devlock) { devlock_release(c->device); tr.holds_devlock = false; }
     if (sync_err != hipSuccess) { tr.poisoned = true; return hip_fail(sync_err, "hipStreamSynchronize(sweep)"); }
     int err[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(err, tr.err, sizeof(err), hipMemcpyDeviceToHost));

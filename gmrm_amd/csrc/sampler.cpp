@@ -34,6 +34,8 @@ struct Chain {                       // class Phenotype, the host-resident part
     std::vector<int> comp;
     std::vector<double> acum, mave, msig;
     bool stepping = false;
+    long long steps_taken = 0;       // gmrm_sampler_step calls of the open per-step sweep
+    bool abandoned = false;          // a per-step sweep was left after steps had been taken: effects and residual may no longer agree
 };
 
 const char CKP_MAGIC[8] = {'G', 'M', 'R', 'M', 'C', 'K', 'P', '1'};                // checkpoint files (gmrm_sampler_save / _load)
@@ -139,6 +141,23 @@ static const char* busy_reason(const gmrm_sampler* s) {
     }
     return nullptr;
 }
+// ... or a sweep in parts has finished some of its parts but not the last: the components are partly rewritten, the old
+// effects are still current and the residual already holds the finished parts' updates -- nothing to save or to close.
+static const char* open_parts_reason(const gmrm_sampler* s) {
+    for (int t = 0; t < s->ctx->T; t++)
+        if (s->ctx->tr[t].part_next != 0) return "a sweep in parts is open (launch and finish its remaining parts first)";
+    return nullptr;
+}
+// A per-step sweep was abandoned after steps had been taken (gmrm_sampler_abort_steps): the caller has applied the
+// residual updates of some of those steps -- in a group possibly to some replicas only -- while the device keeps the
+// effects of the last completed sweep.  Sweeping on would sample against a residual that no set of effects explains.
+static const char* abandoned_reason(const gmrm_sampler* s) {
+    for (int t = 0; t < s->ctx->T; t++)
+        if (s->ch[t].abandoned)
+            return "a per-step sweep was abandoned after steps had been taken: the residual may hold updates of effects that were "
+                   "dropped; replace the chain state (gmrm_sampler_load) before going on";
+    return nullptr;
+}
 
 // bayes.cpp:348-358: add the previous mu back, (it == 1) initial sigmae, draw the new mu
 int gmrm_sampler_draw_mu(gmrm_sampler* s, int it, double* mu_drawn) {
@@ -160,6 +179,8 @@ int gmrm_sampler_begin_parts(gmrm_sampler* s, const double* mu_use) {
     if (!s || !mu_use) return fail(GMRM_EINVAL, "null argument");
     gmrm_ctx* ctx = s->ctx;
     if (const char* why = busy_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_begin_parts: ") + why);
+    if (const char* why = open_parts_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_begin_parts: ") + why);
+    if (const char* why = abandoned_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_begin_parts: ") + why);
     for (int t = 0; t < ctx->T; t++) {
         Chain& c = s->ch[t];
         c.mu = mu_use[t];
@@ -270,8 +291,11 @@ static int begin_steps_body(gmrm_sampler* s, const double* mu_use);
 
 // Leave a per-step sweep that cannot be completed (an error inside _begin_steps / _step, or in another shard of a
 // group): the residual gets this shard's mu back (what the next gmrm_sampler_draw_mu would add: c.mu is cleared), the
-// device keeps the effects / components of the last completed sweep, the host copies are dropped.  The RNG streams have
-// advanced: the chain can go on, it is no longer the chain it was.  Idempotent.
+// device keeps the effects / components of the last completed sweep, the host copies are dropped.  If no step had been
+// taken the chain can go on (the RNG streams have advanced: it is no longer the chain it was).  If steps HAD been taken the
+// caller has applied some of their residual updates (gmrm_update_eps_from) and the library cannot know which: the chain is
+// marked abandoned and every entry that would sweep on refuses until gmrm_sampler_load replaces the state.
+// Idempotent.
 int gmrm_sampler_abort_steps(gmrm_sampler* s) {
     if (!s) return fail(GMRM_EINVAL, "null sampler");
     gmrm_ctx* ctx = s->ctx;
@@ -280,6 +304,8 @@ int gmrm_sampler_abort_steps(gmrm_sampler* s) {
         Chain& c = s->ch[t];
         if (!c.stepping) continue;
         c.stepping = false;
+        if (c.steps_taken > 0) c.abandoned = true;
+        c.steps_taken = 0;
         if (int r = gmrm_offset_eps(ctx, t, c.mu)) rc = r;
         c.mu = 0.0;
     }
@@ -289,6 +315,8 @@ int gmrm_sampler_abort_steps(gmrm_sampler* s) {
 int gmrm_sampler_begin_steps(gmrm_sampler* s, const double* mu_use) {
     if (!s || !mu_use) return fail(GMRM_EINVAL, "null argument");
     if (const char* why = busy_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_begin_steps: ") + why);
+    if (const char* why = open_parts_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_begin_steps: ") + why);
+    if (const char* why = abandoned_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_begin_steps: ") + why);
     const int rc = begin_steps_body(s, mu_use);
     if (rc != GMRM_OK) {                                          // phenotypes already switched over go back
         const std::string keep = gmrm_last_error();
@@ -304,6 +332,7 @@ static int begin_steps_body(gmrm_sampler* s, const double* mu_use) {
         Chain& c = s->ch[t];
         c.mu = mu_use[t];
         c.stepping = true;                                        // from here on an abort has to add mu back
+        c.steps_taken = 0;
         if (int r = gmrm_offset_eps(ctx, t, -c.mu)) return r;
         if (s->shuffle && !c.preshuffled) gm::shuffle(s->mimic_hydra ? c.dist_d : c.dist_m, c.midx.data(), ctx->M);
         c.preshuffled = false;
@@ -337,6 +366,7 @@ int gmrm_sampler_step(gmrm_sampler* s, int mrki, int* mloc_out, double* dbeta3) 
     for (int t = 0; t < ctx->T; t++) {
         Chain& c = s->ch[t];
         if (!c.stepping) return fail(GMRM_ESTATE, "gmrm_sampler_step outside gmrm_sampler_begin_steps .. _end_steps");
+        c.steps_taken++;
         if (c.sigmag[mgrp] == 0.0) {                                               // bayes.cpp:396-400
             c.acum[mloc] = 1.0;
             c.betas[mloc] = 0.0;
@@ -407,6 +437,7 @@ int gmrm_sampler_end_steps(gmrm_sampler* s, int* cass, double* beta_sqn) {
         Chain& c = s->ch[t];
         if (!c.stepping) return fail(GMRM_ESTATE, "gmrm_sampler_end_steps without gmrm_sampler_begin_steps");
         c.stepping = false;
+        c.steps_taken = 0;
         if (ctx->M > 0) {
             if (int r = gmrm_set_betas(ctx, t, c.betas.data())) return r;
             if (int r = gmrm_set_comp(ctx, t, c.comp.data())) return r;
@@ -431,6 +462,10 @@ int gmrm_sampler_end_sweep(gmrm_sampler* s, int* cass, double* beta_sqn) {
         Chain& c = s->ch[t];
         if (ctx->tr[t].in_flight)                       // (a sweep in parts has finished its last part already)
             if (int r = finish_one(s, t)) { rc = r; continue; }
+        if (ctx->tr[t].part_next != 0) {                // the last part has not run: the new effects are not current yet
+            rc = fail(GMRM_ESTATE, "gmrm_sampler_end_sweep: a sweep in parts is open (launch and finish its remaining parts first)");
+            continue;
+        }
         static const bool prof = std::getenv("GMRM_HOST_PROF") != nullptr;
         const auto ta = std::chrono::steady_clock::now();
         if (ctx->M > 0)
@@ -557,6 +592,8 @@ int gmrm_sampler_save(gmrm_sampler* s, const char* path, int it) {
     if (!s || !path) return fail(GMRM_EINVAL, "null argument");
     gmrm_ctx* ctx = s->ctx;
     if (const char* why = busy_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_save: ") + why);
+    if (const char* why = open_parts_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_save: ") + why);
+    if (const char* why = abandoned_reason(s)) return fail(GMRM_ESTATE, std::string("gmrm_sampler_save: ") + why);
     const std::string tmp = std::string(path) + ".tmp";
     FILE* f = std::fopen(tmp.c_str(), "wb");
     if (!f) return fail(GMRM_EIO, std::string("cannot write checkpoint ") + tmp);
@@ -627,6 +664,8 @@ int gmrm_sampler_load(gmrm_sampler* s, const char* path, int* it_out) {
             if (!good) { rc = fail(GMRM_EINVAL, std::string("checkpoint ") + path + " holds an inconsistent chain state (visit order / components / RNG position)"); break; }
         }
         c.sigmae = sc[0]; c.mu = sc[1]; c.epssum = sc[2]; c.preshuffled = flags[0] != 0;
+        c.abandoned = false;                                       // the whole chain state is replaced: residual, effects, components,
+        ctx->tr[t].part_next = 0; ctx->tr[t].part_last = true;     // visit order, streams -- also what an open sweep in parts left
         if ((rc = gmrm_upload_eps(ctx, t, eps.data())) != GMRM_OK) break;
         if (ctx->M > 0) {
             if ((rc = gmrm_set_betas(ctx, t, betas.data())) != GMRM_OK) break;

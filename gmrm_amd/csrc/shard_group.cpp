@@ -72,6 +72,17 @@ struct gmrm_group {
     bool use_rccl = false;
     std::vector<double> hq, hsum;             // host staging
     double exchange_ms = 0.0;
+    // shards in ascending device order: the order in which their sweeps are launched (each launch takes its device's
+    // inter-process lock, capi.cpp: two hosts that take the devices in one global order cannot wait for each other crosswise)
+    std::vector<int> by_device;
+    const std::vector<int>& launch_order() {
+        if ((int)by_device.size() != n) {
+            by_device.resize(n);
+            for (int r = 0; r < n; r++) by_device[r] = r;
+            std::stable_sort(by_device.begin(), by_device.end(), [&](int a, int b) { return ctx[a]->device < ctx[b]->device; });
+        }
+        return by_device;
+    }
 };
 
 #define HIPG(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(GMRM_EHIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -177,7 +188,7 @@ extern "C" int gmrm_group_iterate(gmrm_group* g, int it) {
     // the previous shard's next-iteration shuffle: ~0.6 ms per 125 000 markers, several ms of skew at eight shards); the
     // shuffles and the end-of-sweep downloads (effects, counts, RNG state: blocking copies per device) then run on one
     // host thread per shard.
-    for (int r = 0; r < n; r++)
+    for (int r : g->launch_order())
         if (int rc = gmrm_sampler_launch_sweep(g->smp[r], mu0.data())) return rc;     // launches; returns at once
     std::vector<int> cass((size_t)T * G * K, 0);
     std::vector<double> bsq((size_t)T * G, 0.0);
@@ -241,7 +252,8 @@ extern "C" int gmrm_group_iterate_parts(gmrm_group* g, int it, int k) {
     }
     int rc = GMRM_OK;
     for (int first = 0; first < Mm && rc == GMRM_OK; first += k) {
-        for (int r = 0; r < n && rc == GMRM_OK; r++) {
+        for (int r : g->launch_order()) {                                               // (ascending device order: see launch_order)
+            if (rc != GMRM_OK) break;
             const int Mr = g->ctx[r]->M, f = std::min(first, Mr);
             rc = gmrm_sampler_launch_part(g->smp[r], f, std::min(k, Mr - f));           // launches; returns at once
         }

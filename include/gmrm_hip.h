@@ -67,6 +67,10 @@ typedef struct gmrm_geometry {
     int conc;              /* chains of this context that sweep side by side                     */
     int num_cu;            /* compute units of the device                                        */
     int max_resident_wg;   /* occupancy query x num_cu for the sweep kernel                      */
+    int hw_queues;         /* GPU_MAX_HW_QUEUES as the environment holds it (the library asks for 8 */
+                           /* when it is loaded: a persistent launch holds its queue; chains beyond */
+                           /* the queues run one after another).  0: unset.  Without effect if the  */
+                           /* HIP runtime had been initialised before the library was loaded.       */
 } gmrm_geometry;
 int gmrm_ctx_geometry(const gmrm_ctx* ctx, gmrm_geometry* out);
 

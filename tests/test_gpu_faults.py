@@ -117,10 +117,57 @@ def test_open_per_step_sweep_blocks_other_entries_and_can_be_aborted(gpu, tmp_pa
     got = ctx.get_epsilon(0)                                       # draw_mu's offset stays; begin_steps' is undone
     keep = np.repeat(~np.asarray(inp["isna"][0], dtype=bool), 1)
     assert np.max(np.abs(got[:case.N][keep] - (before[:case.N][keep] + mu_prev))) < 1e-12
+    # a step had been taken, so the caller may have applied residual updates whose effects were dropped with
+    # the host copies -- nothing may sweep on (or save) until the chain state is replaced
+    for call in (lambda: smp.iterate(2), lambda: smp.begin_steps(mu), lambda: smp.save(tmp_path / "y.bin", 1)):
+        with pytest.raises(GmrmError) as ei:
+            call()
+        assert ei.value.code == GMRM_ESTATE and "abandoned" in str(ei.value)
     smp.load(ck)                                                   # and the chain state can be replaced again
     smp.iterate(2)
     want = cases.run_oracle(case, inp, iters=2, canon=True)
     assert np.array_equal(ctx.betas(0), want[0]["betas"][1])
+    smp.close()
+    ctx.close()
+
+
+def test_abort_before_any_step_leaves_a_chain_that_can_go_on(gpu):
+    """gmrm_sampler_abort_steps right after gmrm_sampler_begin_steps (no step taken, no residual update applied): the
+    residual has its mu back and still is y - mu - X beta for the device's effects, so the sampler goes on WITHOUT a
+    reload (iterate after an abort without loading, residual checked against the effects).  And a sweep in
+    parts that has finished only some of its parts cannot be saved or closed."""
+    case = cases.CASE_BY_NAME["small"]
+    inp = cases.make_inputs(case)
+    ctx, (eps0, mask4, nonas) = _setup(case, inp)
+    mave, msig = ctx.compute_markers_statistics(0)
+    smp = gmrm_amd.Sampler(ctx, case.seed, inp["cva"], inp["group_index"])
+    smp.iterate(1)
+    mu = smp.draw_mu(2)
+    smp.begin_steps(mu)
+    smp.abort_steps()                                              # nothing stepped: not "abandoned"
+    smp.iterate(2)                                                 # (draws a fresh mu; the streams have moved on)
+    smp.iterate(3)
+
+    def invariant():
+        hy = smp.hyper(0)
+        g = ctx.predict_g(0, ctx.betas(0))
+        want = eps0[:case.N] - hy.mu - g
+        assert np.max(np.abs(ctx.get_epsilon(0)[:case.N] - want)) < 1e-9
+    invariant()
+    # a sweep in parts, stopped half way
+    mu = smp.draw_mu(4)
+    smp.begin_parts(mu)
+    smp.launch_part(0, 100)
+    smp.finish_part()
+    for call in (lambda: smp.save("/tmp/never.bin", 4), lambda: smp.end_sweep(), lambda: smp.begin_steps(mu)):
+        with pytest.raises(GmrmError) as ei:
+            call()
+        assert ei.value.code == GMRM_ESTATE and "sweep in parts is open" in str(ei.value)
+    smp.launch_part(100, case.M - 100)                             # the remaining part: the sweep can be closed
+    smp.finish_part()
+    cass, bsq = smp.end_sweep()
+    smp.epilogue(cass, bsq)
+    invariant()
     smp.close()
     ctx.close()
 
