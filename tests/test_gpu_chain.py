@@ -77,16 +77,6 @@ def test_screened_sampling_path_is_the_oracle_chain(gpu, monkeypatch, name):
         cases.assert_same_history(got, ref, exact=False, rtol=1e-6)
 
 
-def test_screen_is_taken_by_default_where_runs_are_long(gpu):
-    """The same null-phenotype chain with the library's default knobs: the run-length estimate switches the screen on by
-    itself in the stationary sweeps (what bench.py measures), and the chain is still the oracle's."""
-    case, inp = _null_case(iters=8)
-    got = cases.run_gpu(case, inp)
-    want = cases.run_oracle(case, inp, canon=True)
-    cases.assert_same_history(got, want, exact=True)
-    assert got[0]["nscr"][-1] > 0 and got[0]["nscrt"][-1] >= got[0]["nscr"][-1], (got[0]["nscr"], got[0]["nscrt"])
-
-
 @pytest.mark.parametrize("name,k", [("small", 1), ("small", 37), ("ragged", 64), ("groups", 200), ("groups", 512)])
 def test_sweep_in_parts_is_the_same_chain(gpu, name, k):
     """gmrm_sampler_begin_parts / _launch_part / _finish_part (the building block of `--sync-every k`): one shard that cuts
