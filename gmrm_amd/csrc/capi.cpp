@@ -352,6 +352,8 @@ int gmrm_upload_bed(gmrm_ctx* c, const uint8_t* cols, size_t first, size_t n) {
     if (n == 0) return GMRM_OK;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy2D(c->bed + first * c->stride, c->stride, cols, c->mbytes, c->mbytes, n, hipMemcpyHostToDevice));
+    HIPCHK(launch_recode(c->bed + first * c->stride, n * c->stride, 0, c->tr[0].stream));      // .bed code -> device code (gm_common.h)
+    HIPCHK(hipStreamSynchronize(c->tr[0].stream));
     c->have_bed = true;
     for (auto& tr : c->tr) tr.have_stats = false;
     return GMRM_OK;
@@ -363,6 +365,14 @@ int gmrm_download_bed(gmrm_ctx* c, uint8_t* cols, size_t first, size_t n) {
     if (n == 0) return GMRM_OK;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy2D(cols, c->mbytes, c->bed + first * c->stride, c->stride, c->mbytes, n, hipMemcpyDeviceToHost));
+    {   // device code -> .bed code, byte by byte through a table
+        uint8_t lut[256];
+        for (int v = 0; v < 256; v++) lut[v] = (uint8_t)gm::dcode_to_bed((uint32_t)v);
+        const size_t tot = n * c->mbytes;
+        for (size_t i = 0; i < tot; i++) cols[i] = lut[cols[i]];
+        if (c->N % 4 != 0)                                     // pad bits of the last byte: 00 as PLINK writes them
+            for (size_t m = 0; m < n; m++) cols[m * c->mbytes + c->mbytes - 1] &= (uint8_t)((1u << (2 * (c->N % 4))) - 1u);
+    }
     return GMRM_OK;
 }
 
@@ -521,7 +531,7 @@ int gmrm_update_eps(gmrm_ctx* c, int t, int mloc, const double* dbeta) {
     Trait& tr = c->tr[t];
     double alpha_, beta_;                                      // phenotype.cpp:328-329,385-388 on the residual's grid
     gm::update_values(dbeta[0], dbeta[1], dbeta[2], alpha_, beta_);
-    const double v3 = beta_, v2 = beta_ + alpha_, v0 = v2 + alpha_, v1 = 0.0;   // per .bed code: a = 0, 1, 2, missing
+    const double v0 = beta_, v1 = beta_ + alpha_, v2 = v1 + alpha_, v3 = 0.0;   // per device code: a = 0, 1, 2, missing
     HIPCHK(launch_update(tr.eps, c->bed + (size_t)mloc * c->stride, tr.namask2, c->stride, v0, v1, v2, v3, tr.stream));
     HIPCHK(hipStreamSynchronize(tr.stream));
     return GMRM_OK;
@@ -547,7 +557,7 @@ int gmrm_update_eps_from(gmrm_ctx* c, int t, gmrm_ctx* src, int mloc, const doub
     }
     double alpha_, beta_;                                      // phenotype.cpp:328-329,385-388 on the residual's grid
     gm::update_values(dbeta[0], dbeta[1], dbeta[2], alpha_, beta_);
-    const double v3 = beta_, v2 = beta_ + alpha_, v0 = v2 + alpha_, v1 = 0.0;   // per .bed code: a = 0, 1, 2, missing
+    const double v0 = beta_, v1 = beta_ + alpha_, v2 = v1 + alpha_, v3 = 0.0;   // per device code: a = 0, 1, 2, missing
     HIPCHK(launch_update(tr.eps, col, tr.namask2, c->stride, v0, v1, v2, v3, tr.stream));
     HIPCHK(hipStreamSynchronize(tr.stream));
     return GMRM_OK;

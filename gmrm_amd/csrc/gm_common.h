@@ -24,6 +24,20 @@ namespace gm {
 GM_HD double code_a(int c) { return c == 0 ? 2.0 : (c == 2 ? 1.0 : 0.0); }
 GM_HD double code_b(int c) { return c == 1 ? 0.0 : 1.0; }
 
+// ---- the genotype block as the DEVICE holds it ("device code", round 4) ----------------------------------
+// HBM keeps the .bed layout (marker-major columns, four individuals per byte, LSB first) but the 2-bit field is
+// recoded once, when a block arrives (gmrm_upload_bed / gmrm_load_bed_file / gmrm_synth_bed), so that it IS the
+// reference's dotp_lut_a value:
+//   .bed 00 (a = 2, b = 1) -> 10      .bed 10 (a = 1, b = 1) -> 01      .bed 11 (a = 0, b = 1) -> 00      .bed 01 (missing) -> 11
+// Every kernel reads this code: the sweep kernel's loaders then move column slices HBM -> LDS with no register
+// pass in between (global_load_lds) and feed the matrix cores from registers as they land; the per-call kernels index
+// their (a, b) table with it.  gmrm_download_bed converts back.  A missing genotype is field value 3; an individual
+// without a phenotype is forced to 3 by OR-ing the inverted NA mask (namask2: 11 = phenotype present).
+GM_HD uint32_t bed_to_dcode(uint32_t w) { return (~w & 0xAAAAAAAAu) | ((w ^ (w >> 1)) & 0x55555555u); }
+GM_HD uint32_t dcode_to_bed(uint32_t d) { return (~d & 0xAAAAAAAAu) | ((~(d >> 1) ^ d) & 0x55555555u); }
+GM_HD double dcode_a(int c) { return c == 3 ? 0.0 : (double)c; }
+GM_HD double dcode_b(int c) { return c == 3 ? 0.0 : 1.0; }
+
 // ---- order-independent summation -------------------------------------------------
 // split2(x): q1 = x rounded to a multiple of 2^-22, q2 = (x - q1) rounded to a multiple
 // of 2^-53, remainder (< 2^-54) dropped.  For |x| < 2^8 and <= 2^22 terms scaled by

@@ -19,7 +19,7 @@ constexpr int GMAX = 64;
 struct SweepArgs {
     int N, M, W, Wpad, G, K;
     size_t stride;                 // bytes per marker column in HBM (ceil(N/4) padded to 16)
-    const uint8_t* bed;            // [M][stride] 2-bit genotypes
+    const uint8_t* bed;            // [M][stride] 2-bit genotypes in the device code (gm_common.h)
     const uint8_t* namask2;        // [stride] 2-bit NA mask (11 = phenotype present)
     const int* order;              // [M] visit order (local marker ids)
     const int* group;              // [M] group of each local marker
@@ -76,6 +76,7 @@ hipError_t launch_sumsq(const double* eps, const uint8_t* namask2 /*or null*/, s
                         double* outmax, hipStream_t st);
 hipError_t launch_marker_stats(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, int nonas,
                                double* mave, double* msig, uint8_t* nomiss, hipStream_t st);
+hipError_t launch_recode(uint8_t* bed, size_t nbytes, int back, hipStream_t st);   // .bed code <-> device code, in place
 hipError_t launch_synth(uint8_t* bed, size_t stride, int N, int M, int S, uint64_t seed,
                         double maf, double miss, hipStream_t st);
 hipError_t launch_predict_g(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* mave,

@@ -8,6 +8,7 @@
 // (hipMemcpy2DAsync: file rows of ceil(N/4) bytes into the 16-byte padded device stride).
 #include "../../include/gmrm_hip.h"
 #include "gm_host.h"
+#include "gm_internal.h"
 
 #include <hip/hip_runtime.h>
 
@@ -100,6 +101,7 @@ extern "C" int gmrm_load_bed_file(gmrm_ctx* c, const char* path, size_t file_fir
             t_read += now_s() - tr0;
             HIPCHK_I(hipMemcpy2DAsync(c->bed + m0 * c->stride, c->stride, buf[b], mbytes, mbytes, nm, hipMemcpyHostToDevice, st));
             HIPCHK_I(hipEventRecord(ev[b], st));
+            HIPCHK_I(gm::launch_recode(c->bed + m0 * c->stride, nm * c->stride, 0, st));   // .bed code -> device code (gm_common.h), behind the copy
             used[b] = true;
         }
         HIPCHK_I(hipStreamSynchronize(st));

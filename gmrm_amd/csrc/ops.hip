@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_dot(const uint8_t* __restrict__ col, co
                                              size_t nwords, double* out4) {
     __shared__ double2 lut[4];
     __shared__ double red[4][4];
-    if (threadIdx.x < 4) lut[threadIdx.x] = make_double2(code_a(threadIdx.x), code_b(threadIdx.x));
+    if (threadIdx.x < 4) lut[threadIdx.x] = make_double2(dcode_a(threadIdx.x), dcode_b(threadIdx.x));   // indexed by the device code
     __syncthreads();
     double sa1 = 0.0, sa2 = 0.0, sb1 = 0.0, sb2 = 0.0;
     const uint32_t* cw = reinterpret_cast<const uint32_t*>(col);
@@ -71,7 +71,7 @@ hipError_t launch_dot(const uint8_t* col, const uint8_t*, const double* eps, siz
     return hipGetLastError();
 }
 
-// ---- update: eps_i += val[code_i], code forced to 01 (-> val 0) where the phenotype is NA
+// ---- update: eps_i += val[code_i] (device code: val[a] for a = 0, 1, 2, val[3] = 0), code forced to 3 where the phenotype is NA
 // Thread = two individuals (half a column byte, 16 bytes of the residual): a wave instruction touches 1 KB of contiguous
 // residual (one thread per column dword of 16 individuals read 64 lines per instruction: 5.4 us for 500k individuals).
 __global__ __launch_bounds__(256) void k_update(double* __restrict__ eps, const uint8_t* __restrict__ col,
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ eps, const 
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += (size_t)gridDim.x * blockDim.x) {
         const uint32_t sh = 4u * (uint32_t)(p & 1);
         const uint32_t m = ((uint32_t)namask2[p >> 1] >> sh) & 0xFu;
-        const uint32_t c = (((uint32_t)col[p >> 1] >> sh) & m) | (~m & 0x5u);
+        const uint32_t c = (((uint32_t)col[p >> 1] >> sh) | ~m) & 0xFu;
         double2 e = e2[p];
         e.x += val[c & 3u];
         e.y += val[(c >> 2) & 3u];
@@ -191,11 +191,11 @@ __global__ __launch_bounds__(256) void k_marker_stats(const uint8_t* __restrict_
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t p = mm[i] & 0x55555555u;
-            const uint32_t lo = ww[i] & 0x55555555u;
+            const uint32_t lo = ww[i] & 0x55555555u;                 // device code: field = a (10: a = 2, 01: a = 1, 00: a = 0), 11 = missing
             const uint32_t hi = (ww[i] >> 1) & 0x55555555u;
-            n0 += __popc(p & ~lo & ~hi);
-            n2 += __popc(p & ~lo & hi);
-            n3 += __popc(p & lo & hi);
+            n0 += __popc(p & ~lo & hi);                              // n0, n2, n3 keep the .bed codes' names: a = 2, 1, 0
+            n2 += __popc(p & lo & ~hi);
+            n3 += __popc(p & ~lo & ~hi);
         }
     }
     n0 = wave_sum_i(n0); n2 = wave_sum_i(n2); n3 = wave_sum_i(n3);
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_marker_stats(const uint8_t* __restrict_
         s += (double)n3 * (v3 * v3);
         mave[m] = av;
         msig[m] = 1.0 / __builtin_sqrt(s / ((double)nonas - 1.0));
-        nomiss[m] = (n0 + n2 + n3 == nonas) ? 1 : 0;      // no code 01 among the phenotyped individuals
+        nomiss[m] = (n0 + n2 + n3 == nonas) ? 1 : 0;      // no missing genotype among the phenotyped individuals
     }
 }
 
@@ -217,6 +217,24 @@ hipError_t launch_marker_stats(const uint8_t* bed, const uint8_t* namask2, size_
                                double* mave, double* msig, uint8_t* nomiss, hipStream_t st) {
     if (M <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_marker_stats, dim3((M + 3) / 4), dim3(256), 0, st, bed, namask2, stride, M, nonas, mave, msig, nomiss);
+    return hipGetLastError();
+}
+
+// ---- .bed code <-> device code over a range of columns (gm_common.h), in place, 16 bytes per thread
+__global__ __launch_bounds__(256) void k_recode(uint4* __restrict__ p, size_t nvec, int back) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        uint4 v = p[i];
+        if (back) { v.x = dcode_to_bed(v.x); v.y = dcode_to_bed(v.y); v.z = dcode_to_bed(v.z); v.w = dcode_to_bed(v.w); }
+        else      { v.x = bed_to_dcode(v.x); v.y = bed_to_dcode(v.y); v.z = bed_to_dcode(v.z); v.w = bed_to_dcode(v.w); }
+        p[i] = v;
+    }
+}
+hipError_t launch_recode(uint8_t* bed, size_t nbytes, int back, hipStream_t st) {     // nbytes: a multiple of 16 (whole columns)
+    if (nbytes == 0) return hipSuccess;
+    const size_t nvec = nbytes / 16;
+    size_t blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(k_recode, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint4*>(bed), nvec, back);
     return hipGetLastError();
 }
 
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ bed, size_t
                 out |= (uint8_t)(code << (2 * k));
             }
         }
-        bed[i] = out;
+        bed[i] = (uint8_t)bed_to_dcode(out);                        // stored in the device code (gm_common.h)
     }
 }
 
@@ -330,7 +348,7 @@ __global__ __launch_bounds__(256) void k_predict_g(const uint8_t* __restrict__ b
     const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;          // BW-byte word of every column
     const bool live = w * BW < stride;                                // (threads beyond the column still help with the tables)
     const uint32_t nam = live ? reinterpret_cast<const word_t*>(namask2)[w] : 0u;
-    const uint32_t keep = nam, force = ~nam & (BW == 1 ? 0x55u : 0x5555u);
+    const uint32_t force = ~nam & (BW == 1 ? 0xFFu : 0xFFFFu);     // NA individuals read "missing" (device code 3)
     double acc[NI];
 #pragma unroll
     for (int i = 0; i < NI; i++) acc[i] = 0.0;
@@ -361,7 +379,7 @@ __global__ __launch_bounds__(256) void k_predict_g(const uint8_t* __restrict__ b
         for (int u = 0; u < U; u++) wd[u] = wn[u];
         if (builder) {
             double tv = 0.0;
-            if (nb_ != 0.0) tv = (((code_a(tc) - nmv) * code_b(tc)) * nms) * nb_;
+            if (nb_ != 0.0) tv = (((dcode_a(tc) - nmv) * dcode_b(tc)) * nms) * nb_;
             s_tv[par][tu][tc] = tv;
         }
         if (m0 + U < M) request(m0 + U);
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(256) void k_predict_g(const uint8_t* __restrict__ b
         const char* tvb = reinterpret_cast<const char*>(&s_tv[par][0][0]);
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t x = (wd[u] & keep) | force;
+            const uint32_t x = wd[u] | force;
 #pragma unroll
             for (int i = 0; i < NI; i++)
                 acc[i] += *reinterpret_cast<const double*>(tvb + u * 32 + (((x >> (2 * i)) & 3u) << 3));
@@ -538,13 +556,12 @@ __global__ __launch_bounds__(256) void k_assoc_mfma(const uint8_t* __restrict__ 
                 uint32_t f[4];
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
-                    const uint32_t x = (w4[d] & nm[d]) | (~nm[d] & LO);      // NA individuals read "missing" (01)
-                    const uint32_t nl = ~x & LO;                             // low bit clear: codes 00 (a = 2) and 10 (a = 1)
-                    const uint32_t t1 = (x >> 1) & nl;                       // a = 1
-                    const uint32_t t2 = ~(x >> 1) & nl;                      // a = 2
+                    const uint32_t x = w4[d] | ~nm[d];                       // NA individuals read "missing" (device code 3)
+                    const uint32_t t1 = x & ~(x >> 1) & LO;                  // a = 1 (01)
+                    const uint32_t t2 = (x >> 1) & ~x & LO;                  // a = 2 (10)
                     n1[q] += __popc(t1);
                     n2[q] += __popc(t2);
-                    f[d] = t1 | (t2 << 1);                                   // the 2-bit field now holds a
+                    f[d] = t1 | (t2 << 1);                                   // the field holds a, 0 where the genotype is missing
                 }
                 const as_v4i a0 = {(int)(f[0] & M0), (int)(f[1] & M0), (int)(f[2] & M0), (int)(f[3] & M0)};
                 const as_v4i a1 = {(int)(f[0] & (M0 << 2)), (int)(f[1] & (M0 << 2)), (int)(f[2] & (M0 << 2)), (int)(f[3] & (M0 << 2))};
@@ -728,7 +745,7 @@ __device__ __forceinline__ uint32_t pg_transpose16(uint32_t x, const PgLane& c) 
     return x;
 }
 // .bed code -> genotype value in the 2-bit field (00 -> 2, 10 -> 1, 11 -> 0, 01 (missing) -> 3), as sweep.hip's ring
-__device__ __forceinline__ uint32_t pg_recode(uint32_t w) { return (~w & 0xAAAAAAAAu) | ((w ^ (w >> 1)) & 0x55555555u); }
+__device__ __forceinline__ uint32_t pg_recode(uint32_t w) { return w; }   // (the block is stored in the device code since round 4)
 
 template <bool DIRTY>
 __global__ __launch_bounds__(256) void k_pg_mfma(const uint8_t* __restrict__ bed, size_t stride, int M, const uint8_t* __restrict__ planes,

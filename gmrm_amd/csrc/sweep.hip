@@ -1148,8 +1148,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #pragma unroll 1
             for (int p = from + lpj; p < to; p += PPI) {
                 uint4 v = *reinterpret_cast<const uint4*>(a.bed + (size_t)a.order[p] * a.stride + cb);
-                v.x = recode_codes(v.x); v.y = recode_codes(v.y); v.z = recode_codes(v.z); v.w = recode_codes(v.w);
-                *ring_chunk(p, lci) = v;
+                *ring_chunk(p, lci) = v;                   // (HBM holds the device code: gm_common.h)
             }
         }
         __syncthreads();
@@ -1295,7 +1294,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                         sl = sl >= RPOS ? sl - RPOS : sl;
                         if (o < nc) {
                             uint4 v;
-                            v.x = recode_codes(pf[i].x); v.y = recode_codes(pf[i].y); v.z = recode_codes(pf[i].z); v.w = recode_codes(pf[i].w);
+                            v.x = pf[i].x; v.y = pf[i].y; v.z = pf[i].z; v.w = pf[i].w;
                             *reinterpret_cast<uint4*>(ring + (size_t)sl * SB + 16 * (lci ^ ((p_first + i * PPI) & (CPP - 1)))) = v;
                         }
                     }
