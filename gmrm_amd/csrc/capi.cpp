@@ -228,8 +228,6 @@ static int ctx_create_body(gmrm_ctx* c, int device, int N, int M, int Mt, int S,
                                      " resident workgroups (occupancy query x compute units)");
     }
     env_int("GMRM_NB_FACTOR16", 8, 256, &c->nb_factor16);
-    env_int("GMRM_PF_AHEAD16", 0, 16, &c->pf_ahead16);
-    env_int("GMRM_SPEC_FACTOR16", 1, 4096, &c->spec_factor16);
     env_int("GMRM_CROSS_FRAC16", 1, 16, &c->cross_frac16);
     if (const char* e = std::getenv("GMRM_CROSS_DENSITY")) {
         const double v = std::atof(e);
@@ -369,9 +367,7 @@ int gmrm_download_bed(gmrm_ctx* c, uint8_t* cols, size_t first, size_t n) {
         uint8_t lut[256];
         for (int v = 0; v < 256; v++) lut[v] = (uint8_t)gm::dcode_to_bed((uint32_t)v);
         const size_t tot = n * c->mbytes;
-        for (size_t i = 0; i < tot; i++) cols[i] = lut[cols[i]];
-        if (c->N % 4 != 0)                                     // pad bits of the last byte: 00 as PLINK writes them
-            for (size_t m = 0; m < n; m++) cols[m * c->mbytes + c->mbytes - 1] &= (uint8_t)((1u << (2 * (c->N % 4))) - 1u);
+        for (size_t i = 0; i < tot; i++) cols[i] = lut[cols[i]];   // (a bijection on bytes: pad bits come back as they were uploaded)
     }
     return GMRM_OK;
 }
@@ -765,9 +761,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
         a.trace = tr.trace;
     }
     a.nb_factor16 = c->nb_factor16;
-    a.spec_factor16 = c->spec_factor16;
     a.screen_min_run16 = c->screen_min_run16;
-    a.pf_ahead16 = c->pf_ahead16;
     a.miss_mode = tr.miss_mode;
     if (std::getenv("GMRM_FORCE_MIXED")) a.miss_mode = 1;     // diagnostic: run any block through the per-marker-layout kernel
     // The walk may cross markers whose effect was non-zero: when no marker of the block has a missing genotype among the

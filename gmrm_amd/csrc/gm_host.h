@@ -66,9 +66,8 @@ struct gmrm_ctx {
     bool concurrent = true, have_bed = false, have_groups = false;
     double cross_density = 0.01;    // launch the kernel that crosses stops when at least this fraction of the block's markers is in the model (env GMRM_CROSS_DENSITY)
     int cross_frac16 = 9;           // the walk crosses a marker with a non-zero effect when at least this many sixteenths of the batch lie behind it (env GMRM_CROSS_FRAC16)
-    int batch_init = 16, nb_factor16 = 24, spec_factor16 = 64;   // sweep schedule knobs (env GMRM_NB_FACTOR16 / GMRM_SPEC_FACTOR16)
+    int batch_init = 16, nb_factor16 = 24;                        // sweep schedule knobs (env GMRM_NB_FACTOR16)
     int screen_min_run16 = 16 * 48;                               // the sampling screen is tried from this recent run length on (env GMRM_SCREEN_MIN_RUN16)
-    int pf_ahead16 = 16;                                          // sixteenths of the current batch the prefetch assumes walked (env GMRM_PF_AHEAD16)
 };
 
 namespace gm {

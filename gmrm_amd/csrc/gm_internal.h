@@ -9,8 +9,8 @@
 namespace gm {
 
 constexpr int SW_TPB  = 256;   // threads per workgroup of the sweep kernel (4 wavefronts)
-constexpr int SW_VMAX = 384;   // exchanged values per batch: 4 per marker (sa1,sa2,sb1,sb2) or 2 per marker + 2 per batch in the
-                               // no-missing-genotype layout (<= 120 markers), plus one per marker behind a crossed stop
+constexpr int SW_VMAX = 512;   // exchanged values per batch: 4 per marker (sa1,sa2,sb1,sb2) or 2 per marker + 2 per batch in the
+                               // no-missing-genotype layout (<= 240 markers), plus one per marker behind a crossed stop
 constexpr int NSTOP = 2;       // markers with a non-zero effect the walk may cross inside one batch (sweep.hip, "continuation")
 constexpr int KMAX = 8;
 constexpr int GMAX = 64;
@@ -47,15 +47,14 @@ struct SweepArgs {
     int batch_init;
     unsigned long long* trace;     // diagnostic build: [W][64][8] wall-clock stamps of rounds 2000..2063, or null
     int nb_factor16;               // next batch >= nb_factor16/16 x the run-length EMA, as a power of two (default 24 = 1.5x)
-    int pf_ahead16;                // the prefetch requests slices up to pos + nb * pf_ahead16 / 16 + ring: 16 assumes the batch is walked to its end
-    int spec_factor16;             // speculate when EMA >= spec_factor16/16 batches (default 64 = 4x: rarely pays)
     int screen_min_run16;          // the sampling screen is tried when the run-length EMA (1/16 marker) is at least this
     int miss_mode;                 // markers with a missing genotype among the phenotyped individuals: 0 none, 1 some, 2 all
     unsigned long long spin_ticks; // every grid-wide wait gives up after this many s_memrealtime ticks (100 MHz)
-    // LDS carve of this launch (sweep.hip, carve_for: depends on G, K): byte offsets of the component counts, the per-group
-    // tables, the planes and the genotype ring; ring capacity in order positions and the multiplier of `% rpos`
-    int lds_cass, lds_tab, lds_pln, lds_ring, rpos;
-    unsigned rpos_magic;
+    // LDS carve of this launch (sweep.hip, carve_for: depends on G, K and the kernel): byte offsets of the component counts, the
+    // per-group tables, the planes and the LDS tiles; the number of LDS tile slots (with the multiplier of `% nl`) and the length of
+    // the tile window that follows from it
+    int lds_cass, lds_tab, lds_pln, lds_ring, nl, win;
+    unsigned nl_magic;
     int cross;                     // > 0: the walk may cross a marker whose effect was non-zero when at least cross/16 of the batch
                                    // lies behind it (a crossing costs about half a round; 0: never)
 };

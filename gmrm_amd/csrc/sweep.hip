@@ -28,21 +28,20 @@
 // the batch is then stale.  The residual update is applied and the next batch starts after
 // that marker.  Results are exactly those of the one-marker-at-a-time loop.
 //
-// Pipelining.  While the totals of batch g are in flight, every wavefront already computes and
-// publishes the dots of batch g+1, assuming g ends without a residual update; g+1 is then
-// promoted, otherwise discarded and a fresh batch starts after the stopping marker.  A miss costs a
-// whole batch of dots, so this is switched on only when the recent run length is several batches
-// (spec_factor16; at the measured update rates it rarely is).
-//
-// Genotype stream.  The visit order is known for the whole sweep, so each workgroup keeps a ring
-// of RPOS column slices in LDS (16-byte chunks XOR-swizzled by position so that 64 lanes reading
-// 64 different slices hit different banks).  Wavefronts 1-3 fetch the slices of upcoming positions
-// as coalesced 16-byte loads during the sampling step (in which they are otherwise idle), hold them
-// in AGPRs, and recode + park them in the ring one round later, while wavefront 0 waits for the next
-// totals.  (Individuals without a phenotype have residual 0, hence all-zero digit planes: phase A
-// needs no mask; the update applies it.)
-// Wavefront 3 does the same for the per-marker inputs of the sampling step (marker id, group,
-// previous effect, mave, msig).
+// Genotype stream (round 4).  The visit order is known for the whole sweep, so each workgroup keeps a WINDOW of upcoming
+// order positions on chip, in tiles of 16 positions (tile T = positions 16 T .. 16 T + 15, what one MFMA takes as rows).
+// A tile has a fixed home by its number: most live in LDS (15 tile slots of 8 KB at R = 2, 16-byte chunks XOR-swizzled by
+// position so that 64 lanes reading 64 slices hit different banks), three of every eight live in the REGISTERS of
+// wavefronts 1-3 (one each, in the lane layout the matrix instruction takes operand A in: 32 AGPRs per tile at R = 2) --
+// the register file of a compute unit is three times its LDS, and a batch may only be as long as what is resident.
+// HBM holds the columns in the device code (gm_common.h: the 2-bit field is the genotype value), so nothing is recoded on
+// the way: LDS tiles are filled by global_load_lds_dwordx4 (HBM -> LDS, no register pass, the swizzle applied to the
+// source address), register tiles by global_load_dwordx4 into AGPRs.  The loads of the tiles a walk has freed are issued
+// by wavefronts 1-3 while wavefront 0 samples the next batch, and are waited for one round later: nobody waits for HBM.
+// (Individuals without a phenotype have residual 0, hence all-zero digit planes: phase A needs no mask; the update
+// applies it.)
+// Wavefronts 1-3 do the same for the per-marker inputs of the sampling step (marker id, group,
+// previous effect, mave, msig): a 256-position ring in LDS.
 //
 // Exchange per batch (placement-independent, gfx950: private L2 per XCD).  "The data is the
 // flag": every exchanged double travels as two 8-byte granules {32 data bits, tag = generation + 1}
@@ -66,65 +65,93 @@ namespace gm {
 template <int R> struct Geo {
     static constexpr int SB = SW_TPB * R;                 // slice bytes per workgroup (= genotype bytes = plane records)
     static constexpr int CPP = SB / 16;                   // 16-byte chunks per position
-    static constexpr int RPOS_MAX = R == 4 ? 96 : 240;    // ring capacity in order positions: at most this, and what the LDS left by the
-                                                          // per-group tables holds (SweepArgs::rpos, sweep_carve below)
-    static constexpr int BMAXF = RPOS_MAX / 2;            // markers per batch, no-missing layout (2 values/marker)
-    static constexpr int NL = 192;                        // loader threads (wavefronts 1-3)
-    static constexpr int PPI = NL / CPP;                  // positions covered by one load instruction
-    static constexpr int PFG = 4;                         // loads per wave-uniform branch
-    static constexpr int PFN = ((BMAXF + PPI - 1) / PPI + PFG - 1) / PFG * PFG;   // loads per loader thread per round
+    static constexpr int SS = CPP / 4;                    // super-steps of phase A: 4 chunks = 256 individuals, one chunk per lane group
+    static constexpr int TILE_B = 16 * SB;                // bytes of a tile: the slices of 16 consecutive order positions
+    static constexpr int GPT = TILE_B / 1024;             // global_load_lds_dwordx4 instructions per LDS tile (1 KiB per wave-instruction)
+    static constexpr int PPG = 16 / GPT;                  // positions one of them covers
+    // Homes of the tiles (by tile number T): RPER of every 8 consecutive tiles live in registers -- tile T with T & 7 = w in
+    // the registers of wavefront w = 1..3, slot (T >> 3) % NP -- the others in LDS, slot (index among the LDS tiles) % nl.
+    // At R = 1 a tile is 4 KB and LDS holds more tiles than a batch can use: no register tiles.  At R = 4 a register tile
+    // costs 64 registers: one slot per wavefront.
+    static constexpr int RPER = R == 1 ? 0 : 3;
+    static constexpr int NP = R == 2 ? 3 : (R == 4 ? 1 : 0);
+    static constexpr int NLMAX = R == 1 ? 30 : (R == 2 ? 15 : 7);    // LDS tile slots at most (what fits beside the rest decides: carve_for)
     // Planes of operand B (one byte per individual): the seven digit planes of the residual (four signed base-256 digits of
-    // its part on the 2^-22 grid, three of the rest on the 2^-44 grid) and two planes for the genotype values of markers
-    // the walk may cross (NSTOP).  Plane n starts at n * PSTRIDE + (n >> 2) * 64 bytes (n < 7), stop plane s at
+    // its part on the 2^-22 grid, three of the rest on the 2^-44 grid) and, in the kernels that cross stops, two planes for the
+    // genotype values of those markers (NSTOP).  Plane n starts at n * PSTRIDE + (n >> 2) * 64 bytes (n < 7), stop plane s at
     // (7 + s) * PSTRIDE + 64: in phase A a 16-lane LDS access group reads 16 bytes of each plane, and these offsets
     // put the reads of the nine planes on different bank quads (0,16,32,48,128,144,160,176,192 mod 256).
     static constexpr int PSTRIDE = 4 * SB + 16;
-    static constexpr int NPLANES = 7 + NSTOP;
-    static constexpr int PLANES = NPLANES * PSTRIDE + 64; // bytes of all planes
-    static_assert(NL % CPP == 0 && PPI >= 1, "loader mapping");
-    static_assert(2 * BMAXF + 2 + BMAXF <= SW_VMAX, "exchange rows");
+    static_assert(GPT * PPG == 16 && PPG * SB == 1024, "LDS-DMA mapping");
 };
+template <int R, bool CONT> constexpr int planes_bytes() { return (7 + (CONT ? NSTOP : 0)) * Geo<R>::PSTRIDE + 64; }
+// the longest batch: 240 markers where two values per marker are exchanged and nothing is crossed (four passes of the sampling
+// wavefront); 128 in the other layouts (two passes, as before: their batches end at the first marker in the model or run out
+// of exchange slots long before)
+template <int MODE, bool CONT> constexpr int batch_cap() { return (MODE == 0 && !CONT) ? 240 : 128; }
 
 // ---- LDS carve (bytes, all multiples of 16) --------------------------------------------
-constexpr int L_VAL  = 64;                      // (free)
 constexpr int L_CTL  = 96;                      // int[16]      control words
 constexpr int L_RED  = 160;                     // double[8]    reducer scratch (two rows)
 constexpr int L_WSQ  = 224;                     // double[4][2] per-wavefront sum of q1 / q2
-constexpr int L_M    = 288;                     // diagnostic stamps (64 B at +64)
+constexpr int L_AB   = 288;                     // int[4]       per-wavefront sums of a crossed stop's two planes (all-dirty layout)
+[[maybe_unused]] constexpr int L_M = 288;       // diagnostic stamps (64 B at +64)
 constexpr int L_RNG0 = 416;                     // uint32[624]  current MT block (untempered)
 constexpr int L_RNG1 = L_RNG0 + 2496;           // uint32[624]  next MT block
-constexpr int L_SUM  = L_RNG1 + 2496;           // int64[SW_VMAX]  per-batch integer sums of this workgroup
+constexpr int L_SUM  = L_RNG1 + 2496;           // int64[SW_VMAX]  per-batch integer sums of this workgroup (plain stores: a tile has one owner)
 constexpr int META_POS = 256;                   // per-marker inputs of the sampling step, ring over order positions
 constexpr int L_META = L_SUM + SW_VMAX * 8;     // int m[256], int g[256], double beta[256], mave[256], msig[256]
 constexpr int L_NM   = L_META + META_POS * 32;  // uint8[256]: "no missing genotype" flag of the marker at each ring position
-constexpr int L_TOT  = L_NM + META_POS;         // double[SW_VMAX]: the batch totals as wavefront 0 fetched them
+constexpr int L_TOT  = L_NM + META_POS;         // double[SW_VMAX]: the batch totals as wavefront 0 fetched them.  The same bytes serve, at
+                                                // other times of the round: the reducers' row accumulators (between publish and poll) and
+                                                // the staged slices of register-home markers for the residual update (after the walk)
 constexpr int L_ZSP  = L_TOT + SW_VMAX * 8;     // int64[16][2]: missing-genotype terms of a batch's few dirty markers (sparse_z)
 constexpr int L_ZNX  = L_ZSP + 16 * 16;         // double[129] (+ pad): the x table of the normal ziggurat (gm_rng.h), copied at kernel start
-constexpr int L_UPD  = L_ZNX + 130 * 8;         // the residual updates of the round: int n, pos[3]; double val[3][4] (by ring code)
-constexpr int L_VAR  = L_UPD + 16 + 96 + 16;    // from here on the carve depends on G, K (sweep_carve): component counts int[G*K],
-                                                // per-group tables double[G*(1+3K)], the planes, the genotype ring
+constexpr int L_UPD  = L_ZNX + 130 * 8;         // the residual updates of the round: int n, pos[3]; double val[3][4] (by device code)
+constexpr int L_VAR  = L_UPD + 16 + 96 + 16;    // from here on the carve depends on G, K (carve_for): component counts int[G*K],
+                                                // per-group tables double[G*(1+3K)], the planes, the LDS tiles
 static_assert(L_VAR % 16 == 0, "LDS carve");
-constexpr int L_MIN = 84 * 1024;                // request > 80 KiB so that exactly one workgroup fits per CU
 constexpr int L_TOTAL = 160 * 1024;
+constexpr int NSTAGE = 3;                       // slices staged for one round's residual updates (the crossed stops and the last one)
 
-// The part of the carve that depends on the launch (number of groups and components): offsets and the ring capacity.
-struct Carve { int cass, tab, pln, ring, rpos; unsigned magic; };
-template <int R> static Carve carve_for(int G, int K) {
+// The part of the carve that depends on the launch (number of groups and components, the kernel's planes): offsets, the number
+// of LDS tile slots that fit and the tile window that follows from it.
+struct Carve { int cass, tab, pln, ring, nl, win; unsigned nl_magic; };
+// the longest run of consecutive tiles in which every tile has a slot of its own: at most nl LDS tiles, at most NP register tiles
+// of any one wavefront (pattern of Geo: tiles T & 7 = 1, 2, 3 in registers when RPER == 3)
+static int window_tiles(int rper, int nl, int np) {
+    for (int w = 96; w >= 1; w--) {
+        bool ok = true;
+        for (int start = 0; start < 8 && ok; start++) {
+            int nlds = 0, nreg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = start; t < start + w; t++) {
+                const int j = t & 7;
+                if (rper && j >= 1 && j <= 3) nreg[j]++; else nlds++;
+            }
+            if (nlds > nl) ok = false;
+            for (int j = 1; j <= 3; j++) if (nreg[j] > np) ok = false;
+        }
+        if (ok) return w;
+    }
+    return 0;
+}
+template <int R, bool CONT> static Carve carve_for(int G, int K) {
     Carve c;
     c.cass = L_VAR;
     c.tab = c.cass + (G * K * 4 + 15) / 16 * 16;
     const int tabd = G * (1 + 3 * K);
-    c.pln = c.tab + (tabd * 8 + 15) / 16 * 16;        // always in LDS: large tables take positions from the ring
-    c.ring = c.pln + Geo<R>::PLANES;
-    int rp = (L_TOTAL - c.ring) / Geo<R>::SB;
-    if (rp > Geo<R>::RPOS_MAX) rp = Geo<R>::RPOS_MAX;
-    c.rpos = rp & ~1;
-    c.magic = (unsigned)((1ull << 32) / (unsigned)c.rpos) + 1u;       // p % rpos = p - rpos * umulhi(p, magic) for p < 2^32 / rpos
+    c.pln = c.tab + (tabd * 8 + 15) / 16 * 16;        // always in LDS: large tables take tile slots
+    c.ring = (c.pln + planes_bytes<R, CONT>() + 1023) / 1024 * 1024;          // LDS-DMA destinations: 1 KiB blocks
+    int nl = (L_TOTAL - c.ring) / Geo<R>::TILE_B;
+    if (nl > Geo<R>::NLMAX) nl = Geo<R>::NLMAX;
+    c.nl = nl < 1 ? 0 : nl;
+    c.win = c.nl ? window_tiles(Geo<R>::RPER, c.nl, Geo<R>::NP) : 0;
+    c.nl_magic = c.nl ? (unsigned)((1ull << 32) / (unsigned)c.nl) + 1u : 0u;    // x % nl = x - nl * umulhi(x, magic) for x < 2^32 / nl (x < 2^22 here)
     return c;
 }
-template <int R> constexpr int lds_total() { return L_TOTAL; }
 
 enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD, C_TOTF, C_RANGE, C_PLN, C_SCRMIN, C_NSCRT, C_NSCR };
+static_assert(C_NSCR < 16, "control words");
 
 size_t sweep_lds_bytes() { return (size_t)L_TOTAL; }
 
@@ -186,6 +213,22 @@ __device__ __forceinline__ void get_row6(const unsigned long long* base, int lan
                  "global_load_dwordx4 %5, %7, off offset:1024 sc1\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]) : "v"(g), "v"(g2) : "memory");
+}
+
+// ... and up to 512 (a batch of 240 markers in the two-value layout)
+__device__ __forceinline__ void get_row8(const unsigned long long* base, int lane, u32x4 (&d)[8]) {
+    const unsigned long long* g = base + 2 * lane;
+    const unsigned long long* g2 = g + 512;
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                 "global_load_dwordx4 %1, %8, off offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:2048 sc1\n\t"
+                 "global_load_dwordx4 %3, %8, off offset:3072 sc1\n\t"
+                 "global_load_dwordx4 %4, %9, off sc1\n\t"
+                 "global_load_dwordx4 %5, %9, off offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %6, %9, off offset:2048 sc1\n\t"
+                 "global_load_dwordx4 %7, %9, off offset:3072 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]) : "v"(g), "v"(g2) : "memory");
 }
 
 // ---- cross-lane helpers for the wavefront reductions (gfx950: v_permlane{16,32}_swap, DPP) ----
@@ -535,8 +578,8 @@ struct Walk {
 // the sums of the markers behind it (exact integers, see above) and walks on, crossing further registered stops itself.
 // Two instantiations of the same code: the first stays the straight-line two-pass code the compiler makes of it when
 // nothing can resume inside (its loop-carried state is small), the second is a general loop entered ~0.3 times per round.
-template <int K, int CK, bool HOT, class TP>
-__device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, TP tab,
+template <int K, int CK, bool HOT, bool LONGB, class TP>
+__device__ __forceinline__ void walk_piece(Walk& w, int nb, int mpos0, int G, char* smem, TP tab,
                                            const LaneIn& lin0, const LaneIn& lin1, Totals& tq0, Totals& tq1,
                                            const Draws draws, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass,
                                            int ns, int ps0, int ps1) {
@@ -606,6 +649,21 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, T
         in.beta_old = part ? lin1.beta_old : lin0.beta_old; in.mave = part ? lin1.mave : lin0.mave; in.msig = part ? lin1.msig : lin0.msig;
         Totals tt;
         tt.t0 = part ? tq1.t0 : tq0.t0; tt.t1 = part ? tq1.t1 : tq0.t1; tt.t2 = part ? tq1.t2 : tq0.t2; tt.t3 = part ? tq1.t3 : tq0.t3;
+        if constexpr (LONGB) {
+            // positions 128.. of a long batch (two-value layout, nothing crossed; up to 240 markers: four passes).  The walk
+            // gets here in a minority of the rounds: their inputs stay in the LDS meta ring and their totals where the
+            // poll parked them, instead of in registers carried through every round.
+            if (part >= 2) {                                         // (uniform)
+                const int pp = base + lane < nb ? base + lane : nb - 1;
+                const int sl = (mpos0 + pp) & (META_POS - 1);
+                const int* mr_m = reinterpret_cast<const int*>(smem + L_META);
+                const int* mr_g = mr_m + META_POS;
+                const double* mr_beta = reinterpret_cast<const double*>(mr_g + META_POS);
+                in = LaneIn{mr_m[sl], mr_g[sl], mr_beta[sl], mr_beta[META_POS + sl], mr_beta[2 * META_POS + sl]};
+                const double* s_tot = reinterpret_cast<const double*>(smem + L_TOT);
+                tt = Totals{s_tot[2 * pp], s_tot[2 * pp + 1], s_tot[2 * nb], s_tot[2 * nb + 1]};
+            }
+        }
         const bool act = lane < nbp && lane >= lo;
         const int m = in.m, g = in.g;
         const double beta_old = in.beta_old;
@@ -616,7 +674,7 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, T
         const int prefix = __popcll(use_mask & ((1ull << lane) - 1ull));
         const int cursor0 = cursor;
         double prob = part ? draws.p1 : draws.p0;                        // bayes.cpp:435: word cursor0 + prefix of the stream (sample_prepare)
-        if (repeek) prob = unif_from_word(rs.peek(cursor0 + prefix));
+        if (repeek || (LONGB && part >= 2)) prob = unif_from_word(rs.peek(cursor0 + prefix));
 
         SSTAMP(0);   // inputs, RNG peek
         int kc = 0;
@@ -757,8 +815,8 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int G, char* smem, T
     w.stopped = stopped; w.planned = planned; w.repeek = repeek;
 }
 
-template <int K, int CK, class TP>
-__device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
+template <int K, int CK, bool LONGB, class TP>
+__device__ __forceinline__ void sample_batch_body(int nb, int mpos0, int bmax_, int nbf16, int G, char* smem, TP tab,
                                                   const LaneIn& lin0, const LaneIn& lin1, Totals& tq0, Totals& tq1,
                                                   const Draws draws, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass,
                                                   int ns, int ps0, int ps1) {
@@ -771,10 +829,10 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
     w.cursor = ctl[C_CURSOR]; w.run = 2 * nb; w.nupd = 0; w.ncross = 0; w.from = 0; w.ndone = nb;
     w.stopped = false; w.planned = false; w.repeek = false; w.q = -1; w.at = 0; w.ai = 0; w.bi = 0; w.xs = 0;
     w.screen = ctl[C_EMA] >= ctl[C_SCRMIN];                              // recent run length (1/16 marker): a pass of 64 markers has a fair chance to hold no stop
-    walk_piece<K, CK, true>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
+    walk_piece<K, CK, true, LONGB>(w, nb, mpos0, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
     if (CK != 0) {
         if (__builtin_expect(w.q >= 0, 0))                           // (uniform) the walk met a marker it may cross
-            walk_piece<K, CK, false>(w, nb, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
+            walk_piece<K, CK, false, LONGB>(w, nb, mpos0, G, smem, tab, lin0, lin1, tq0, tq1, draws, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
     }
     if (lane == 0) {
         ctl[C_UPD] = w.nupd;
@@ -794,13 +852,13 @@ __device__ __forceinline__ void sample_batch_body(int nb, int bmax_, int nbf16, 
 }
 
 // K = 4 (the reference's example mixtures) is inlined into the kernel; other K share out-of-line copies.
-template <int K, int CK, class TP>
-__device__ __noinline__ void sample_batch(int nb, int bmax_, int nbf16, int G, char* smem, TP tab,
+template <int K, int CK, bool LONGB, class TP>
+__device__ __noinline__ void sample_batch(int nb, int mpos0, int bmax_, int nbf16, int G, char* smem, TP tab,
                                           const LaneIn& lin0, const LaneIn& lin1, const Totals& tot0, const Totals& tot1,
                                           double p0, double p1, double sigmae, double inv2sige, double nm1, const SampleOut out, bool writer, int l_cass,
                                           int ns, int ps0, int ps1) {
     Totals tq0 = tot0, tq1 = tot1;
-    sample_batch_body<K, CK>(nb, bmax_, nbf16, G, smem, tab, lin0, lin1, tq0, tq1, Draws{p0, p1}, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
+    sample_batch_body<K, CK, LONGB>(nb, mpos0, bmax_, nbf16, G, smem, tab, lin0, lin1, tq0, tq1, Draws{p0, p1}, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
 }
 
 // rank of batch position p among the dirty markers of the batch (dm0: positions 0..63, dm1: 64..127)
@@ -823,35 +881,27 @@ __device__ __forceinline__ bool poll_totals(int nb, int nv, unsigned long long d
     Spin sp;
     sp.start(spin_limit);
     bool bad = false;
-    if (nv <= 256) {                             // (uniform) the usual case: four 16-byte loads per lane cover the row
-        u32x4 d[4];
+    auto look = [&](auto ng_tag) {                // NG groups of 64 values: one look = NG 16-byte loads per lane, one round trip
+        constexpr int NG = decltype(ng_tag)::value;
+        u32x4 d[NG];
         for (;;) {
-            get_row4(Ttg, lane, d);
+            if constexpr (NG == 4) get_row4(Ttg, lane, d);
+            else if constexpr (NG == 6) get_row6(Ttg, lane, d);
+            else get_row8(Ttg, lane, d);
             bool ok = true;
 #pragma unroll
-            for (int k = 0; k < 4; k++)
+            for (int k = 0; k < NG; k++)
                 if (64 * k + lane < nv) ok &= (d[k].y == tag && d[k].w == tag);
             if (__all(ok)) break;
             if (sp.expired(abort_word)) { bad = true; break; }
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < NG; k++)
             s_tot[64 * k + lane] = __longlong_as_double((long long)(((unsigned long long)d[k].z << 32) | d[k].x));
-    } else {
-        u32x4 d[6];
-        for (;;) {
-            get_row6(Ttg, lane, d);
-            bool ok = true;
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-                if (64 * k + lane < nv) ok &= (d[k].y == tag && d[k].w == tag);
-            if (__all(ok)) break;
-            if (sp.expired(abort_word)) { bad = true; break; }
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-            s_tot[64 * k + lane] = __longlong_as_double((long long)(((unsigned long long)d[k].z << 32) | d[k].x));
-    }
+    };
+    if (nv <= 256) look(std::integral_constant<int, 4>{});            // (uniform) the usual case
+    else if (nv <= 384) look(std::integral_constant<int, 6>{});
+    else look(std::integral_constant<int, 8>{});
     Totals t0{0.0, 0.0, 0.0, 0.0}, t1{0.0, 0.0, 0.0, 0.0};
     const double sq1 = s_tot[2 * nb], sq2 = s_tot[2 * nb + 1];
     if ((dm0 | dm1) == 0ull) {                   // (uniform) the usual case: no dirty marker in the batch
@@ -951,16 +1001,17 @@ __device__ __forceinline__ long long wave_sum64(long long x) {
 #endif
 constexpr int SPARSE_ZMAX = GM_SPARSE_ZMAX;
 
-// One super-step's LDS operands: the 64 bytes of the lane's digit plane (operand B of the four MFMAs) and the
-// lane's 16-byte chunk of its marker's slice (operand A before the field masks) for the ONE or TWO tiles the
-// wavefront works on (B is shared by both).  The reads are inline asm so that they can be issued a whole
-// super-step ahead of their use: hipcc does not count them, the matching stage_wait does (N = LDS reads
-// issued after this stage's; LDS returns in order).  Native vector types: "+v" operands must be registers.
-template <int NT> struct Stage { v4i b0, b1, b2, b3; u32x4 w[NT]; };
-template <int NT> __device__ __forceinline__ Stage<NT> stage_read(uint32_t baddr, uint32_t waddr0, uint32_t waddr1) {
-    Stage<NT> st;
+// One super-step's LDS operands: the 64 bytes of the lane's digit plane (operand B of the four MFMAs) and the lane's
+// 16-byte chunk of its marker's slice (operand A before the field masks) for the NLD = 0, 1 or 2 LDS-home tiles of the
+// pass (B is shared by all its tiles; a register-home tile's operand A is in the wavefront's registers already).  The reads
+// are inline asm so that they can be issued a whole super-step ahead of their use: hipcc does not count them, the
+// matching stage_wait does (N = LDS reads issued after this stage's; LDS returns in order).  Native vector types: "+v"
+// operands must be registers.
+template <int NLD> struct Stage { v4i b0, b1, b2, b3; u32x4 w[NLD ? NLD : 1]; };
+template <int NLD> __device__ __forceinline__ Stage<NLD> stage_read(uint32_t baddr, uint32_t waddr0, uint32_t waddr1) {
+    Stage<NLD> st;
     v4i b0, b1, b2, b3; u32x4 w0, w1;
-    if constexpr (NT == 2) {
+    if constexpr (NLD == 2) {
         asm volatile("ds_read_b128 %0, %6\n\t"
                      "ds_read_b128 %1, %6 offset:16\n\t"
                      "ds_read_b128 %2, %6 offset:32\n\t"
@@ -968,30 +1019,41 @@ template <int NT> __device__ __forceinline__ Stage<NT> stage_read(uint32_t baddr
                      "ds_read_b128 %4, %7\n\t"
                      "ds_read_b128 %5, %8"
                      : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(w0), "=&v"(w1) : "v"(baddr), "v"(waddr0), "v"(waddr1) : "memory");
-        st.w[1] = w1;
-    } else {
+        st.w[0] = w0; st.w[1] = w1;
+    } else if constexpr (NLD == 1) {
         asm volatile("ds_read_b128 %0, %5\n\t"
                      "ds_read_b128 %1, %5 offset:16\n\t"
                      "ds_read_b128 %2, %5 offset:32\n\t"
                      "ds_read_b128 %3, %5 offset:48\n\t"
                      "ds_read_b128 %4, %6"
                      : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(w0) : "v"(baddr), "v"(waddr0) : "memory");
+        st.w[0] = w0;
+    } else {
+        asm volatile("ds_read_b128 %0, %4\n\t"
+                     "ds_read_b128 %1, %4 offset:16\n\t"
+                     "ds_read_b128 %2, %4 offset:32\n\t"
+                     "ds_read_b128 %3, %4 offset:48"
+                     : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(baddr) : "memory");
+        st.w[0] = u32x4{0u, 0u, 0u, 0u};
     }
-    st.b0 = b0; st.b1 = b1; st.b2 = b2; st.b3 = b3; st.w[0] = w0;
+    st.b0 = b0; st.b1 = b1; st.b2 = b2; st.b3 = b3;
     return st;
 }
-// wait until this stage's reads have landed; `later` = true: the NT + 4 reads of the next stage stay in flight
-template <int NT, bool LATER> __device__ __forceinline__ Stage<NT> stage_wait(const Stage<NT> st) {
+// wait until this stage's reads have landed; LATER = true: the 4 + NLD reads of the next stage stay in flight
+template <int NLD, bool LATER> __device__ __forceinline__ Stage<NLD> stage_wait(const Stage<NLD> st) {
     v4i b0 = st.b0, b1 = st.b1, b2 = st.b2, b3 = st.b3; u32x4 w0 = st.w[0];
-    Stage<NT> r;
-    if constexpr (NT == 2) {
+    Stage<NLD> r;
+    if constexpr (NLD == 2) {
         u32x4 w1 = st.w[1];
         if constexpr (LATER) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(w0), "+v"(w1) : : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(w0), "+v"(w1) : : "memory");
         r.w[1] = w1;
-    } else {
+    } else if constexpr (NLD == 1) {
         if constexpr (LATER) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(w0) : : "memory");
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(w0) : : "memory");
+    } else {
+        if constexpr (LATER) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : : "memory");
     }
     r.b0 = b0; r.b1 = b1; r.b2 = b2; r.b3 = b3; r.w[0] = w0;
     return r;
@@ -999,45 +1061,56 @@ template <int NT, bool LATER> __device__ __forceinline__ Stage<NT> stage_wait(co
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
+// HBM -> LDS without a register pass: every lane's 16 bytes at `gsrc` (any address per lane: a gather) land at LDS byte
+// address lds_dst + 16 * lane (lds_dst wave-uniform, passed in M0).  Counted by vmcnt like any load; hipcc does not know.
+// M0 is the compiler's: saved and restored inside the statement (tools/micro/glds_probe.hip: destinations up to 160 KB).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst);      // (uniform by construction; the compiler does not always see it)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
 
 // MODE: which markers of the block have a missing genotype among the phenotyped individuals ("dirty"; host: the
 // flags of the marker statistics) -- 0: none, 1: some (per-marker flags decide), 2: all.
-// CONT: the walk may cross markers whose effect was non-zero ("continuation", above; fast layout only).  A kernel of its own:
-// the code it adds costs the rounds that cross nothing ~3 % (register allocation), so the host launches it only for
+// CONT: the walk may cross markers whose effect was non-zero ("continuation", above; fast layout and all-dirty layout).  A kernel
+// of its own: the code it adds costs the rounds that cross nothing ~3 % (register allocation), so the host launches it only for
 // sweeps in which enough markers are in the model for the crossings to pay (capi.cpp, gmrm_sweep_launch).
 template <int R, int MODE, bool CONT>
 __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     static_assert(!CONT || MODE == 0 || MODE == 2, "continuation: the fast layout and the all-dirty layout");
     constexpr int CK = !CONT ? 0 : (MODE == 0 ? 1 : 2);   // 1: no marker has a missing genotype (among the phenotyped), 2: every marker may
     constexpr bool FAST = MODE == 0;
+    constexpr bool LONGB = MODE == 0 && !CONT;            // batches of up to 240 markers: four passes of the sampling wavefront
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GE = Geo<R>;
     constexpr int NI = 4 * R;                        // individuals per thread
     constexpr int ND = NI / 4;                       // dwords of a column slice a thread takes its genotypes from
-    constexpr int SB = GE::SB, CPP = GE::CPP, PPI = GE::PPI, PFN = GE::PFN, PFG = GE::PFG;
-    const int RPOS = a.rpos;                         // ring capacity (positions): what the LDS left by the per-group tables holds
-    const unsigned rpos_magic = a.rpos_magic;
-    auto rmod = [&](int p) -> int { return p - RPOS * (int)__umulhi((unsigned)p, rpos_magic); };   // p % RPOS
-    constexpr int SS = CPP / 4;                      // super-steps: 4 chunks = 256 individuals, one chunk per lane group
+    constexpr int SB = GE::SB, CPP = GE::CPP, SS = GE::SS, TILE_B = GE::TILE_B, GPT = GE::GPT, PPG = GE::PPG;
+    constexpr int RPER = GE::RPER, NP = GE::NP, NPX = NP ? NP : 1;
     constexpr int PST = GE::PSTRIDE;                 // bytes per digit plane
+    constexpr int BCAP = batch_cap<MODE, CONT>();
+    constexpr int NPASS = BCAP > 128 ? 4 : 2;        // groups of 64 batch positions
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wg = blockIdx.x;
     const int W = a.W, K = a.K, G = a.G;
-    // FAST: every marker of the block is free of missing genotypes among the phenotyped individuals (host:
-    // all_nomiss) -- 2 exchanged values per marker and the code for missing genotypes is not even compiled in.
-    // Otherwise the markers' flags decide per marker (2 more values) and per tile of 16 (a second MFMA set).
-    const int BMAX = RPOS / 2;                       // cap of the batch-size estimate: two batches live in the ring (dirty markers shorten a batch: 2 more slots each)
+    const int NLS = a.nl;                            // LDS tile slots of this launch
+    const unsigned nl_magic = a.nl_magic;
+    const int WIN = a.win;                           // tiles [pos >> 4, (pos >> 4) + WIN) have slots of their own
 
     int* ctl = reinterpret_cast<int*>(smem + L_CTL);
     uint32_t* s_rng0 = reinterpret_cast<uint32_t*>(smem + L_RNG0);
     uint32_t* s_rng1 = reinterpret_cast<uint32_t*>(smem + L_RNG1);
     int* s_cass = reinterpret_cast<int*>(smem + a.lds_cass);
-    unsigned long long* s_sum = reinterpret_cast<unsigned long long*>(smem + L_SUM);
+    long long* s_sum = reinterpret_cast<long long*>(smem + L_SUM);
     double* s_red = reinterpret_cast<double*>(smem + L_RED);
     double* s_wsq = reinterpret_cast<double*>(smem + L_WSQ);
+    int* s_ab = reinterpret_cast<int*>(smem + L_AB);
     long long* s_zsp = reinterpret_cast<long long*>(smem + L_ZSP);
     double* s_tab = reinterpret_cast<double*>(smem + a.lds_tab);
     char* planes = smem + a.lds_pln;
     char* ring = smem + a.lds_ring;
+    char* stage = smem + L_TOT;                      // staged slices of register-home markers (free between the walk and the next poll; NSTAGE * SB <= SW_VMAX * 8)
+    static_assert(NSTAGE * GE::SB <= SW_VMAX * 8, "staging area");
     unsigned* abort_word = a.cnt + 64;
     const unsigned long long spin_limit = a.spin_ticks;
     unsigned long long* Pg = reinterpret_cast<unsigned long long*>(a.P);
@@ -1046,7 +1119,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     for (int i = tid; i < 624; i += SW_TPB) s_rng0[i] = a.rng_state[i];
     for (int i = tid; i < G * K; i += SW_TPB) s_cass[i] = 0;
     for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];
-    for (int i = tid; i < SW_VMAX; i += SW_TPB) s_sum[i] = 0ull;
 #ifdef GM_SWEEP_PROF
     if (tid < 8) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[tid] = 0ull;
 #endif
@@ -1059,7 +1131,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         ctl[C_RANGE] = 0;
         ctl[C_SCRMIN] = a.screen_min_run16; ctl[C_NSCRT] = 0; ctl[C_NSCR] = 0;
         ctl[C_EMA] = 16 * a.batch_init / 2;
-        ctl[C_NBNEXT] = a.batch_init < 16 ? 16 : (a.batch_init > BMAX ? BMAX : a.batch_init);
+        ctl[C_NBNEXT] = a.batch_init < 16 ? 16 : (a.batch_init > BCAP ? BCAP : a.batch_init);
     }
     __syncthreads();
     block_advance(s_rng0, s_rng1, ctl, false);       // S1 = twist(S0)
@@ -1078,7 +1150,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     for (int q = 0; q < NI; q++) eps[q] = valid ? a.eps[4 * (o_byte + (size_t)q) + (size_t)o_fld] : 0.0;
     // NA / out-of-range individuals: their residual is 0 and stays 0, so their digit planes are 0 and
     // phase A may see ANY genotype code for them; only the residual update has to skip them: the owner
-    // thread forces their ring codes to 11 (missing, update value 0) when it reads its bytes in phase C.
+    // thread forces their codes to 3 (missing, update value 0) when it reads its bytes in phase C.
     uint32_t na_or[ND];
 #pragma unroll
     for (int d = 0; d < ND; d++) {
@@ -1087,7 +1159,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     }
     // split the thread's residuals, park their digit planes in LDS, leave the wavefront's sum of
     // q1 / q2 in s_wsq (readers: after the next barrier)
-    auto refresh_planes = [&]() {
+    auto refresh_planes = [&]() __attribute__((always_inline))  {
         double sq1 = 0.0, sq2 = 0.0;
         bool big = false;
         uint32_t pl[7][ND];
@@ -1123,39 +1195,59 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     };
     refresh_planes();
 
-    // ---- loader role (wavefronts 1-3): one 16-byte chunk of PFN upcoming columns per round -----
-    const bool loader = wave != 0;                    // wavefront 0 polls: its loads must not queue behind prefetches
-    const int lt = loader ? tid - 64 : 0;
-    const int lci = lt % CPP, lpj = lt / CPP;         // chunk of the slice, position within a load instruction
-    const size_t cb_true = (size_t)wg * SB + (size_t)lci * 16;
-    // Out-of-range lanes (last workgroup: its slice sticks out of the column) fetch the same chunk of
-    // the PREVIOUS slice: in bounds, never used (their individuals do not exist), contiguous with the
-    // valid lanes' bytes.  The prefetch issue is latency-bound per column (every position is a random
-    // 125 KB column of a 125 GB array): with the surplus lanes at the other end of the column the last
-    // workgroup took twice as long to issue its loads and trailed every round by 2 us.
-    const size_t cb = !loader ? 0 : (cb_true < a.stride ? cb_true : (cb_true >= (size_t)SB ? cb_true - SB : cb_true % a.stride));
-    auto ring_chunk = [&](int p, int chunk) -> uint4* {   // 16-byte chunk `chunk` of order position p
-        return reinterpret_cast<uint4*>(ring + (size_t)rmod(p) * SB + 16 * (chunk ^ (p & (CPP - 1))));
+    // ---- the tile window --------------------------------------------------------------------------------
+    // Tile T = order positions 16 T .. 16 T + 15.  Its home follows from T alone (Geo<R>): register tiles T & 7 = 1, 2, 3 belong
+    // to wavefronts 1, 2, 3 (slot (T >> 3) % NP), the others live in LDS, slot (their index among the LDS tiles) % NLS.
+    // Phase A hands tile T to wavefront T & 3 -- for the register tiles that is their owner.
+    auto is_reg = [&](int T) __attribute__((always_inline)) -> bool { return RPER != 0 && (unsigned)((T & 7) - 1) < 3u; };
+    auto lds_index = [&](int T) __attribute__((always_inline)) -> int { return RPER != 0 ? 5 * (T >> 3) + ((T & 7) == 0 ? 0 : (T & 7) - 3) : T; };
+    auto lds_slot = [&](int T) __attribute__((always_inline)) -> int { const int li = lds_index(T); return li - NLS * (int)__umulhi((unsigned)li, nl_magic); };
+    auto reg_slot = [&](int T) __attribute__((always_inline)) -> int { return NP > 1 ? (T >> 3) % NP : 0; };
+    const bool loader = wave != 0;                    // wavefront 0 polls: its loads must not queue behind tile loads
+    const int mrow = lane & 15, kg = lane >> 4;       // the lane's row of a 16-marker tile / its chunk within a super-step (operand A layout)
+    // Byte offset of chunk c of this workgroup's slice inside a column.  Out-of-range chunks (last workgroup: its slice sticks out
+    // of the column) read the same chunk of the PREVIOUS slice: in bounds, never used (their individuals do not exist).
+    auto chunk_off = [&](int c) __attribute__((always_inline)) -> size_t {
+        const size_t t = (size_t)wg * SB + (size_t)c * 16;
+        return t < a.stride ? t : (t >= (size_t)SB ? t - SB : (size_t)0);     // (a column shorter than one slice: workgroup 0, chunk 0)
     };
-    u32x4 pf[PFN];                                    // in flight / parked in AGPRs (inline asm below owns them)
+    u32x4 rt[NPX][SS];                                // register-home tiles of this wavefront (AGPRs; the inline asm below owns them)
+#pragma unroll
+    for (int k = 0; k < NPX; k++)
+#pragma unroll
+        for (int s2 = 0; s2 < SS; s2++) rt[k][s2] = u32x4{0u, 0u, 0u, 0u};
+    const int ntiles = (a.M + 15) >> 4;
     int pos = 0;
-    int hi = 0;                                       // ring holds order positions [pos, hi)
-    int npf = 0;                                      // positions [hi, hi + npf) are in flight / in registers
+    int t_hi = 0;                                     // tiles [pos >> 4, t_hi) are on chip or on their way (uniform)
 
-    // synchronous ring fill of positions [from, to) (start-up and the rare slow path; kept small)
-    auto fill = [&](int from, int to) {
-        if (loader) {
-#pragma unroll 1
-            for (int p = from + lpj; p < to; p += PPI) {
-                uint4 v = *reinterpret_cast<const uint4*>(a.bed + (size_t)a.order[p] * a.stride + cb);
-                *ring_chunk(p, lci) = v;                   // (HBM holds the device code: gm_common.h)
-            }
+    // one LDS tile: GPT wave-instructions of 1 KiB; lane l of instruction i: chunk slot l % CPP of position i * PPG + l / CPP,
+    // the XOR swizzle applied on the source side
+    auto load_lds_tile = [&](int T, int idl) __attribute__((always_inline))  {        // idl: lane l holds the marker id of position 16 T + (l & 15)
+        const uint32_t dst0 = lds_addr(ring) + (uint32_t)lds_slot(T) * (uint32_t)TILE_B;
+        const int cs = lane & (CPP - 1), pin = lane / CPP;
+#pragma unroll
+        for (int i = 0; i < GPT; i++) {
+            const int pi = i * PPG + pin;             // position within the tile
+            const int id = __builtin_amdgcn_ds_bpermute(pi << 2, idl);
+            const int chunk = cs ^ ((16 * T + pi) & (CPP - 1));
+            const uint8_t* src = a.bed + (size_t)id * a.stride + chunk_off(chunk);
+            glds16(src, dst0 + (uint32_t)i * 1024u);
         }
-        __syncthreads();
+    };
+    // one register tile: lane (mrow, kg) takes chunk 4 s + kg of marker 16 T + mrow, s = 0 .. SS - 1
+    auto load_reg_tile = [&](auto k_tag, int idl) __attribute__((always_inline))  {
+        constexpr int KR = decltype(k_tag)::value;
+        const uint8_t* col = a.bed + (size_t)idl * a.stride;
+#pragma unroll
+        for (int s2 = 0; s2 < SS; s2++) {
+            const uint8_t* src = col + chunk_off(4 * s2 + kg);
+            u32x4& dst = rt[KR][s2];                  // (named outside the asm: a generic lambda captures it only then)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+a"(dst) : "v"(src) : "memory");
+        }
     };
     // ---- per-marker inputs of the sampling step (marker id, group, previous effect, mave, msig):
-    // wavefront 3 fetches them for upcoming order positions (dependent global loads) one
-    // round ahead and parks them in a 256-position LDS ring, so a restart never waits on them.
+    // wavefronts 1-3 fetch them for upcoming order positions (dependent global loads) one round ahead -- two groups of 64
+    // positions each, up to 384 per round -- and park them in a 256-position LDS ring, so a batch never waits on them.
     int* mr_m = reinterpret_cast<int*>(smem + L_META);
     int* mr_g = mr_m + META_POS;
     double* mr_beta = reinterpret_cast<double*>(mr_g + META_POS);
@@ -1166,31 +1258,31 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     int pm_m[2] = {0, 0}, pm_g[2] = {0, 0}, pm_nm[2] = {1, 1};
     double pm_beta[2] = {0.0, 0.0}, pm_mave[2] = {0.0, 0.0}, pm_msig[2] = {1.0, 1.0};
     // in two steps: the marker ids, then -- once they are there -- what hangs on them.  Between the two the caller waits for
-    // something else (the gate of the column prefetch); the second step goes in FRONT of the column loads: a wait for ids
-    // issued behind those would be a wait for the columns (HBM latency), which kept wavefront 3 from the round's barrier
-    // until after wavefront 0 had finished sampling.
-    auto meta_ids = [&](int want) {
+    // something else (the gate of the tile loads); the second step goes in FRONT of the tile loads: a wait for ids
+    // issued behind those would be a wait for the columns (HBM latency).
+    auto meta_ids = [&](int want) __attribute__((always_inline))  {
         if (want > a.M) want = a.M;
         npm = want - mhi;
-        if (npm > 128) npm = 128;
+        if (npm > 384) npm = 384;
         if (npm < 0) npm = 0;
-        if (wave == 3) {
+        if (loader) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                if (64 * h < npm) {
-                    const int p = mhi + 64 * h + lane;
+                const int grp = (wave - 1) + 3 * h;       // this wavefront's groups of 64 positions: wave - 1 and wave + 2
+                if (64 * grp < npm) {
+                    const int p = mhi + 64 * grp + lane;
                     const int pi = p < a.M ? p : a.M - 1;
                     pm_m[h] = a.order[pi];
                 }
             }
         }
     };
-    auto meta_issue = [&](int want) {
-        (void)want;
-        if (wave == 3) {
+    auto meta_issue = [&]() __attribute__((always_inline))  {
+        if (loader) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                if (64 * h < npm) {
+                const int grp = (wave - 1) + 3 * h;
+                if (64 * grp < npm) {
                     pm_g[h] = a.group[pm_m[h]];
                     pm_beta[h] = a.betas_in[pm_m[h]];
                     pm_mave[h] = a.mave[pm_m[h]];
@@ -1200,15 +1292,16 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             }
         }
     };
-    auto meta_commit = [&]() {
+    auto meta_commit = [&]() __attribute__((always_inline))  {
         int nc = pos + META_POS - mhi;
         if (nc > npm) nc = npm;
         if (nc < 0) nc = 0;
-        if (wave == 3) {
+        if (loader) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                if (64 * h + lane < nc) {
-                    const int sl = (mhi + 64 * h + lane) & (META_POS - 1);
+                const int grp = (wave - 1) + 3 * h;
+                if (64 * grp + lane < nc) {
+                    const int sl = (mhi + 64 * grp + lane) & (META_POS - 1);
                     mr_m[sl] = pm_m[h]; mr_g[sl] = pm_g[h]; mr_beta[sl] = pm_beta[h]; mr_mave[sl] = pm_mave[h]; mr_msig[sl] = pm_msig[h];
                     if (MODE == 1) mr_nm[sl] = (uint8_t)pm_nm[h];
                 }
@@ -1217,109 +1310,140 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         mhi += nc;
         npm = 0;
     };
-    auto ensure_meta = [&](int upto) {                 // slow path (uniform): meta ring must hold [.., upto)
+    auto ensure_meta = [&](int upto) __attribute__((always_inline))  {                 // slow path (uniform): meta ring must hold [.., upto)
         if (mhi < upto) meta_commit();
-        while (mhi < upto) { meta_ids(upto); meta_issue(upto); meta_commit(); }
+        while (mhi < upto) { meta_ids(upto); meta_issue(); meta_commit(); }
     };
 
-    // request the slices of positions [hi, want) (at most PFN*PPI); they stay in registers until commit
-    auto prefetch_issue = [&](int want, unsigned gate_tag, const bool with_meta) {
-        if (want > a.M) want = a.M;
-        npf = want - hi;
-        if (npf > PFN * PPI) npf = PFN * PPI;
-        if (npf < 0) npf = 0;
+    // Request tiles [t_hi, t_lim) (at most 16 per call).  LDS tiles are shared out over the loader wavefronts by their index,
+    // a register tile is loaded by its owner: among 16 consecutive tiles a wavefront owns at most two, in different slots, so
+    // the loads of every slot are ONE asm site in the whole kernel (several sites per slot made the register allocator keep a
+    // slot in different registers at different sites, with copies of registers whose loads were in flight in between:
+    // tools/check_prefetch_regs.py).  All marker ids are requested before the first tile load; the tile loads themselves
+    // wait until wavefront 0 has the totals (gate_tag != 0): every memory instruction of a compute unit goes through one
+    // in-order address pipeline, and loads issued while wavefront 0 polls delay its looks.
+    constexpr int JMAXL = RPER ? 4 : 6;               // LDS tiles one wavefront loads per call, at most
+    auto tile_issue = [&](int t_lim, unsigned gate_tag, const bool with_meta) __attribute__((always_inline)) {
+        if (t_lim > t_hi + 16) t_lim = t_hi + 16;
+        if (t_lim < t_hi) t_lim = t_hi;
         if (loader) {
-            // groups of PFG loads behind wave-uniform branches: only about npf/PPI loads are issued and
-            // none waits on a select (indices are clamped, surplus positions are dropped at commit).
-            // All marker ids are requested before the first column load: a wait for ids issued
-            // behind column loads would serialise the groups on HBM latency (loads return in order).
-            int idx[PFN];
-#pragma unroll
-            for (int c8 = 0; c8 < PFN; c8 += PFG) {
-                if (c8 * PPI < npf) {
-#pragma unroll
-                    for (int i = c8; i < c8 + PFG; i++) {
-                        const int p = hi + i * PPI + lpj;
-                        idx[i] = a.order[p < a.M ? p : a.M - 1];
-                    }
+            t_hi = __builtin_amdgcn_readfirstlane(t_hi);
+            t_lim = __builtin_amdgcn_readfirstlane(t_lim);
+            // this wavefront's register tiles among them, by slot (uniform)
+            int tk0 = -1, tk1 = -1, tk2 = -1;
+            if constexpr (NP > 0) {
+                for (int T = t_hi + ((wave - t_hi) & 7); T < t_lim; T += 8) {   // T & 7 == wave (1..3): a register tile of mine
+                    const int k = reg_slot(T);
+                    if (k == 0) tk0 = T; else if (k == 1) tk1 = T; else tk2 = T;
                 }
             }
-            // The column loads are slow to issue (a random 125 KB column of a 125 GB array each) and every memory
-            // instruction of a CU goes through one in-order address pipeline: issued while wavefront 0 polls
-            // for the totals they delay its loads.  So they wait until wavefront 0 has the totals (LDS word);
-            // the marker ids above (L2 hits) are in flight meanwhile.
+            unsigned lmine = 0u;                      // bit T - t_hi: LDS tile T is loaded by this wavefront (uniform)
+            for (int T = t_hi; T < t_lim; T++) {
+                const bool m_ = !is_reg(T) && (1 + lds_index(T) % 3) == wave;
+                lmine |= (m_ ? 1u : 0u) << (T - t_hi);
+            }
+            auto id_of = [&](int T) __attribute__((always_inline)) -> int {     // lane l: the marker at position 16 T + (l & 15)
+                const int p = 16 * T + mrow;
+                return a.order[p < a.M ? p : a.M - 1];
+            };
+            int idr0 = 0, idr1 = 0, idr2 = 0;
+            if (tk0 >= 0) idr0 = id_of(tk0);
+            if (NP > 1 && tk1 >= 0) idr1 = id_of(tk1);
+            if (NP > 2 && tk2 >= 0) idr2 = id_of(tk2);
+            int idl[JMAXL];
+            unsigned mm = lmine;
+#pragma unroll
+            for (int j = 0; j < JMAXL; j++) {
+                idl[j] = 0;
+                if (mm) {                             // (uniform)
+                    const int T = __builtin_amdgcn_readfirstlane(t_hi + (__ffs((int)mm) - 1));
+                    mm &= mm - 1u;
+                    idl[j] = id_of(T);
+                }
+            }
             if (gate_tag != 0u) {
                 Spin sp;
                 sp.start(spin_limit);
                 while (*reinterpret_cast<const volatile int*>(&ctl[C_TOTF]) != (int)gate_tag)
                     if (sp.expired(abort_word)) break;
             }
-            if (with_meta) meta_issue(0);             // (loads that depend on ids requested before the gate: they have landed by now)
-            // The column loads are inline asm on AGPR destinations: the compiler neither waits for them nor
-            // counts them; the only wait is the explicit one in prefetch_commit, a whole round later
-            // (tools/check_prefetch_regs.py checks in the disassembly that nothing touches them in between).
+            if (with_meta) meta_issue();              // (loads that depend on ids requested before the gate: they have landed by now)
+            if constexpr (NP > 0) { if (tk0 >= 0) load_reg_tile(std::integral_constant<int, 0>{}, idr0); }
+            if constexpr (NP > 1) { if (tk1 >= 0) load_reg_tile(std::integral_constant<int, 1>{}, idr1); }
+            if constexpr (NP > 2) { if (tk2 >= 0) load_reg_tile(std::integral_constant<int, 2>{}, idr2); }
+            mm = lmine;
 #pragma unroll
-            for (int c8 = 0; c8 < PFN; c8 += PFG) {
-                if (c8 * PPI < npf) {
-#pragma unroll
-                    for (int i = c8; i < c8 + PFG; i++) {
-                        const uint8_t* src = a.bed + (size_t)idx[i] * a.stride + cb;
-                        asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(pf[i]) : "v"(src) : "memory");
-                    }
+            for (int j = 0; j < JMAXL; j++) {
+                if (mm) {                             // (uniform)
+                    const int T = __builtin_amdgcn_readfirstlane(t_hi + (__ffs((int)mm) - 1));
+                    mm &= mm - 1u;
+                    load_lds_tile(T, idl[j]);
                 }
             }
         }
+        t_hi = t_lim;
     };
-    // recode the requested slices and park them in the ring as far as the window [pos, pos + RPOS) allows
-    // (the rest is dropped and requested again); readers see them after the next barrier.  Called a full
-    // round after the issue -- while wavefront 0 waits for the totals, the loader wavefronts have nothing
-    // else to do -- so nobody waits for HBM and the recoding is off the critical path.
-    auto prefetch_commit = [&]() {
-        int nc = pos + RPOS - hi;
-        if (nc > npf) nc = npf;
-        if (nc < 0) nc = 0;
-        if (loader && nc > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // slot of this thread's first position; later ones are PPI apart (one conditional wrap each)
-            const int p_first = hi + lpj;
-            const int s_first = rmod(p_first);
+    // every tile load issued so far has landed (each wavefront waits for its own; visible to the others after the next barrier)
+    auto tiles_wait = [&]() __attribute__((always_inline))  {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int c8 = 0; c8 < PFN; c8 += PFG) {
-                if (c8 * PPI < nc) {
+        for (int k = 0; k < NPX; k++)
 #pragma unroll
-                    for (int i = c8; i < c8 + PFG; i++) {
-                        asm volatile("" : "+a"(pf[i]));     // the value is defined HERE, after the wait: no use of it can be scheduled earlier
-                        const int o = i * PPI + lpj;
-                        int sl = s_first + i * PPI;
-                        sl = sl >= RPOS ? sl - RPOS : sl;
-                        if (o < nc) {
-                            uint4 v;
-                            v.x = pf[i].x; v.y = pf[i].y; v.z = pf[i].z; v.w = pf[i].w;
-                            *reinterpret_cast<uint4*>(ring + (size_t)sl * SB + 16 * (lci ^ ((p_first + i * PPI) & (CPP - 1)))) = v;
+            for (int s2 = 0; s2 < SS; s2++) asm volatile("" : "+a"(rt[k][s2]));   // the values are defined HERE, after the wait: no use can be scheduled earlier
+    };
+    // The slice of order position p, as the threads read their own genotypes (residual update, stop planes): in its LDS tile,
+    // or -- a register-home marker -- in staging slot `slot`, where its owner has put it (stage_slices).  `swz`: the XOR of the
+    // chunk index (LDS tiles are swizzled by position, staged slices are not).
+    struct SliceAt { const char* base; int swz; };
+    auto slice_at = [&](int p, int slot) __attribute__((always_inline)) -> SliceAt {
+        const int T = p >> 4;
+        if (is_reg(T)) return SliceAt{stage + slot * SB, 0};
+        return SliceAt{ring + (size_t)lds_slot(T) * TILE_B + (size_t)(p & 15) * SB, p & (CPP - 1)};
+    };
+    // Owners copy the slices of the register-home markers among n order positions (at(u), uniform) to the staging slots;
+    // returns whether there was any (uniform): the caller then needs a barrier before anybody reads them.
+    auto stage_slices = [&](int n, auto at) __attribute__((always_inline)) -> bool {
+        bool any = false;
+        if constexpr (NP > 0) {
+#pragma unroll 1
+            for (int u = 0; u < n; u++) {
+                const int p = at(u);
+                const int T = p >> 4;
+                if (!is_reg(T)) continue;             // (uniform)
+                any = true;
+                if ((T & 7) != wave) continue;
+                const int k = reg_slot(T);
+                if (mrow == (p & 15)) {               // the four lanes that hold this marker's chunks
+                    u32x4* d = reinterpret_cast<u32x4*>(stage + u * SB + 16 * kg);
+                    if (k == 0) {
+#pragma unroll
+                        for (int s2 = 0; s2 < SS; s2++) { u32x4 v = rt[0][s2]; asm volatile("" : "+v"(v)); d[4 * s2] = v; }   // (opaque per slot: the three arms must not be merged into one load through a selected address -- rt would then live in scratch)
+                    }
+                    if constexpr (NP > 1) {
+                        if (k == 1) {
+#pragma unroll
+                            for (int s2 = 0; s2 < SS; s2++) { u32x4 v = rt[1][s2]; asm volatile("" : "+v"(v)); d[4 * s2] = v; }   // (opaque per slot: the three arms must not be merged into one load through a selected address -- rt would then live in scratch)
+                        }
+                    }
+                    if constexpr (NP > 2) {
+                        if (k == 2) {
+#pragma unroll
+                            for (int s2 = 0; s2 < SS; s2++) { u32x4 v = rt[2][s2]; asm volatile("" : "+v"(v)); d[4 * s2] = v; }   // (opaque per slot: the three arms must not be merged into one load through a selected address -- rt would then live in scratch)
                         }
                     }
                 }
             }
         }
-        hi += nc;
-        npf = 0;
-    };
-    auto ensure = [&](int upto) {                      // slow path: ring must hold [pos, upto)
-        if (hi < upto) prefetch_commit();
-        if (hi < upto) { fill(hi, upto); hi = upto; }
+        return any;
     };
 
-    // ---- the marker loop, software-pipelined over exchange generations -----------------------
-    // While the totals of the current batch are in flight, every wavefront already computes
-    // and publishes the dots of the NEXT batch, assuming the current one ends without a residual
-    // update.  If it does end that way the next batch is promoted (its partials are already at
-    // the reducers); otherwise it is discarded and a fresh batch starts after the stopping
-    // marker.  Generation g uses tag g+1 and buffer g&1; a buffer is rewritten only after every
+    // ---- the marker loop ---------------------------------------------------------------------------------
+    // Generation g uses tag g+1 and buffer g&1; a buffer is rewritten only after every
     // workgroup has sampled the generation that used it.
     struct Batch { int p0, nb, nv; unsigned gen; bool planned; unsigned long long dm0, dm1; int ns, ps0, ps1; };   // planned: ends at a marker known to stop the walk; dm: dirty positions;
                                                                                                                 // ns, ps: the markers with a non-zero effect the walk may cross (batch positions)
     unsigned gen_next = 0;
-    long long n_upd = 0, n_batch = 0, n_disc = 0, n_planned = 0, n_stale = 0, n_fastb = 0, n_cross = 0;
+    long long n_upd = 0, n_batch = 0, n_planned = 0, n_stale = 0, n_fastb = 0, n_cross = 0, n_short = 0;
     int max_nb = 0;
     bool ok = true;
 #ifdef GM_SWEEP_PROF
@@ -1331,12 +1455,12 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #define PA(i) do { } while (0)
 #endif
 
-    // phase A for positions [b.p0, b.p0 + b.nb) (slices already in the ring) + publish
-    auto compute_publish = [&](Batch& b, LaneIn& li0, LaneIn& li1) {
+    // phase A for positions [b.p0, b.p0 + b.nb) (their tiles are on chip) + publish
+    auto compute_publish = [&](Batch& b, LaneIn& li0, LaneIn& li1) __attribute__((always_inline))  {
 #ifdef GM_SWEEP_PROF
         unsigned long long tpa = tlast;
 #endif
-        lds_barrier();                                // ring / plane / meta writes are visible (no vmcnt drain)
+        lds_barrier();                                // tile / plane / meta writes are visible
         PA(0);
         const int p0 = b.p0;
         // Everything the scan needs from the meta ring is fetched in ONE burst, for ring positions that may lie behind
@@ -1344,6 +1468,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // the batch length is known would put a second and a third LDS round trip on the critical path.
         const int sl0 = (p0 + lane) & (META_POS - 1), sl1 = (p0 + lane + 64) & (META_POS - 1);
         const double rb0 = mr_beta[sl0], rb1 = mr_beta[sl1];
+        double rb2 = 0.0, rb3 = 0.0;
+        if (NPASS > 2) { rb2 = mr_beta[(p0 + lane + 128) & (META_POS - 1)]; rb3 = mr_beta[(p0 + lane + 192) & (META_POS - 1)]; }
         unsigned char rn0 = 1, rn1 = 1;
         if (MODE == 1) { rn0 = mr_nm[sl0]; rn1 = mr_nm[sl1]; }
         LaneIn r0i{0, 0, 0.0, 0.0, 1.0}, r1i{0, 0, 0.0, 0.0, 1.0};
@@ -1382,13 +1508,17 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const bool nz0 = lane < b.nb && rb0 != 0.0;
             const bool nz1 = lane + 64 < b.nb && rb1 != 0.0;
             unsigned long long m0 = __ballot(nz0), m1 = __ballot(nz1);
-            const int first = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : b.nb);
+            int first = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : b.nb);
+            if (NPASS > 2 && first >= b.nb) {         // (uniform) positions 128.. of a long batch
+                const unsigned long long m2 = __ballot(lane + 128 < b.nb && rb2 != 0.0), m3 = __ballot(lane + 192 < b.nb && rb3 != 0.0);
+                first = m2 ? 128 + __ffsll((long long)m2) - 1 : (m3 ? 192 + __ffsll((long long)m3) - 1 : b.nb);
+            }
             b.ns = 0; b.ps0 = 0; b.ps1 = 0;
             // A crossing costs about half a round (the sums behind the marker are patched and decided again, its genotype values
             // become a plane, more values are exchanged): it pays when a good part of the batch lies behind the marker
             const int cross_thr = (b.nb * a.cross + 15) >> 4;   // a.cross: sixteenths of the batch (0: never)
             if (CONT && a.cross && first + 1 < b.nb && first + cross_thr <= b.nb - 1) {   // (uniform)
-                auto pop_first = [&]() -> int {
+                auto pop_first = [&]() __attribute__((always_inline)) -> int {
                     if (m0) { const int f = __ffsll((long long)m0) - 1; m0 &= m0 - 1ull; return f; }
                     if (m1) { const int f = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1ull; return f; }
                     return -1;
@@ -1397,6 +1527,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 int last = pop_first();                          // the stop that ends the batch, if any
                 if (CK == 2) {                                   // 4 slots per marker + 2 for the stop + 2 per marker behind it
                     const int fit = (SW_VMAX - 2 + 2 * b.ps0) / 6;
+                    if (b.nb > fit) b.nb = fit;
+                }
+                if (CK == 1) {                                   // 2 slots per marker + 2 + 1 per marker behind the first stop
+                    const int fit = (SW_VMAX - 2 + b.ps0 + 1) / 3;
                     if (b.nb > fit) b.nb = fit;
                 }
                 if (CK == 1 && NSTOP > 1 && last >= 0 && last + 1 < b.nb && last + cross_thr <= b.nb - 1) {
@@ -1418,10 +1552,22 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         b.dm0 = dm0; b.dm1 = dm1;
         const int nd = __popcll(dm0) + __popcll(dm1);
         const bool all_dirty = MODE == 2 || nd == nb; // then the r-th dirty marker is batch position r
-        // A few dirty markers among clean ones: every tile runs the one-MFMA-set pass (X = sum c' d) and the
+        // A few dirty markers among clean ones: every tile runs the one-MFMA-set pass (X = sum c d) and the
         // missing-genotype term Z of each dirty marker is gathered from the digit planes, one wavefront per
-        // marker (sparse_z below), instead of a second MFMA set over every tile that holds such a marker.
-        const bool sparse_z = MODE == 1 && !all_dirty && nd > 0 && nd <= SPARSE_ZMAX;      // uniform
+        // marker (sparse_z below), instead of a second MFMA set over every tile that holds such a marker.  Only where every
+        // dirty marker of the batch lives in an LDS tile (a register tile's slice is not addressable lane by lane).
+        bool sparse_z = MODE == 1 && !all_dirty && nd > 0 && nd <= SPARSE_ZMAX;      // uniform
+        if constexpr (MODE == 1 && RPER != 0) {
+            if (sparse_z) {
+                unsigned long long r0 = dm0, r1 = dm1;
+                while (r0 | r1) {
+                    int m;
+                    if (r0) { m = __ffsll((long long)r0) - 1; r0 &= r0 - 1ull; }
+                    else    { m = 64 + __ffsll((long long)r1) - 1; r1 &= r1 - 1ull; }
+                    if (is_reg((p0 + m) >> 4)) sparse_z = false;
+                }
+            }
+        }
         {
             const bool a0 = wave == 0 && lane < nb, a1 = wave == 0 && lane + 64 < nb;
             li0 = LaneIn{a0 ? r0i.m : 0, a0 ? r0i.g : 0, a0 ? r0i.beta_old : 0.0, a0 ? r0i.mave : 0.0, a0 ? r0i.msig : 1.0};
@@ -1448,8 +1594,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     else    { m = 64 + __ffsll((long long)r1) - 1; r1 &= r1 - 1ull; }
                     if ((r & 3) == wave) {
                         const int pm = p0 + m;
-                        const char* slice = ring + (size_t)rmod(pm) * SB;
-                        const int swz = pm & (CPP - 1);
+                        const SliceAt sa = slice_at(pm, 0);                              // (an LDS tile: checked above)
+                        const char* slice = sa.base;
+                        const int swz = sa.swz;
                         long long z1 = 0, z2 = 0;
 #pragma unroll
                         for (int q0 = 0; q0 < SB / 4; q0 += 64) {
@@ -1489,97 +1636,105 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
         // The genotype values of the markers the walk may cross, as planes of operand B (columns 8, 9): a_s(i) for the
         // phenotyped individuals, 0 for the others and for a missing genotype.  Every thread writes the bytes of its own
-        // individuals, from the marker's slice in the ring (as in phase C).
+        // individuals, from the marker's slice (as in phase C; a register-home marker's slice is staged by its owner first).
         const int ns = b.ns, ps0 = b.ps0, ps1 = b.ps1;
-        if (CONT && ns > 0) {                         // (uniform)
+        if constexpr (CONT) {
+            if (ns > 0) {                             // (uniform)
+                if (stage_slices(ns, [&](int u) __attribute__((always_inline))  { return p0 + (u ? ps1 : ps0); })) lds_barrier();
 #pragma unroll 1
-            for (int q = 0; q < ns; q++) {
-                const int ps = p0 + (q ? ps1 : ps0);
-                const char* own = ring + (size_t)rmod(ps) * SB + 16 * (o_chunk ^ (ps & (CPP - 1))) + o_jb;
-                uint32_t pv[ND], pb[ND];
-                int suma = 0, sumb = 0;
+                for (int q = 0; q < ns; q++) {
+                    const int ps = p0 + (q ? ps1 : ps0);
+                    const SliceAt sa = slice_at(ps, q);
+                    const char* own = sa.base + 16 * (o_chunk ^ sa.swz) + o_jb;
+                    uint32_t pv[ND], pb[ND];
+                    int suma = 0, sumb = 0;
 #pragma unroll
-                for (int d = 0; d < ND; d++) {
-                    const uint32_t x = ((*reinterpret_cast<const uint32_t*>(own + 4 * d) | na_or[d]) >> (2 * o_fld)) & 0x03030303u;
-                    const uint32_t miss = x & (x >> 1) & 0x01010101u;            // ring code 3: missing genotype (or no phenotype)
-                    pv[d] = x & ~(miss | (miss << 1));
-                    pb[d] = miss ^ 0x01010101u;                                  // b_s: 1 unless missing
-                    suma += (int)((pv[d] * 0x01010101u) >> 24);                  // byte sums (<= 8, <= 4)
-                    sumb += (int)((pb[d] * 0x01010101u) >> 24);
-                }
-                char* dst = planes + (7 + q) * PST + 64 + p0w;
-                if constexpr (ND == 1) *reinterpret_cast<uint32_t*>(dst) = pv[0];
-                else if constexpr (ND == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pv[0], pv[1]);
-                else *reinterpret_cast<uint4*>(dst) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
-                if constexpr (CK == 2) {
-                    // the all-dirty layout has one stop: its second plane holds b_s, and the slice's sums of both planes
-                    // (A_s = sum a_s, B_s = sum b_s over the phenotyped individuals) are exchanged like everything else
-                    char* dstb = planes + 8 * PST + 64 + p0w;
-                    if constexpr (ND == 1) *reinterpret_cast<uint32_t*>(dstb) = pb[0];
-                    else if constexpr (ND == 2) *reinterpret_cast<uint2*>(dstb) = make_uint2(pb[0], pb[1]);
-                    else *reinterpret_cast<uint4*>(dstb) = make_uint4(pb[0], pb[1], pb[2], pb[3]);
-                    int pk = suma | (sumb << 16);                                // both sums of a wavefront fit 16 bits (<= 64 * 32)
+                    for (int d = 0; d < ND; d++) {
+                        const uint32_t x = ((*reinterpret_cast<const uint32_t*>(own + 4 * d) | na_or[d]) >> (2 * o_fld)) & 0x03030303u;
+                        const uint32_t miss = x & (x >> 1) & 0x01010101u;            // code 3: missing genotype (or no phenotype)
+                        pv[d] = x & ~(miss | (miss << 1));
+                        pb[d] = miss ^ 0x01010101u;                                  // b_s: 1 unless missing
+                        suma += (int)((pv[d] * 0x01010101u) >> 24);                  // byte sums (<= 8, <= 4)
+                        sumb += (int)((pb[d] * 0x01010101u) >> 24);
+                    }
+                    char* dst = planes + (7 + q) * PST + 64 + p0w;
+                    if constexpr (ND == 1) *reinterpret_cast<uint32_t*>(dst) = pv[0];
+                    else if constexpr (ND == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(pv[0], pv[1]);
+                    else *reinterpret_cast<uint4*>(dst) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
+                    if constexpr (CK == 2) {
+                        // the all-dirty layout has one stop: its second plane holds b_s, and the slice's sums of both planes
+                        // (A_s = sum a_s, B_s = sum b_s over the phenotyped individuals) are exchanged like everything else
+                        char* dstb = planes + 8 * PST + 64 + p0w;
+                        if constexpr (ND == 1) *reinterpret_cast<uint32_t*>(dstb) = pb[0];
+                        else if constexpr (ND == 2) *reinterpret_cast<uint2*>(dstb) = make_uint2(pb[0], pb[1]);
+                        else *reinterpret_cast<uint4*>(dstb) = make_uint4(pb[0], pb[1], pb[2], pb[3]);
+                        int pk = suma | (sumb << 16);                                // both sums of a wavefront fit 16 bits (<= 64 * 32)
 #pragma unroll
-                    for (int o = 32; o >= 1; o >>= 1) pk += __shfl_xor(pk, o, 64);
-                    if (lane == 0) {
-                        atomicAdd(&s_sum[4 * b.nb + 2], (unsigned long long)(pk & 0xFFFF));
-                        atomicAdd(&s_sum[4 * b.nb + 3], (unsigned long long)(pk >> 16));
+                        for (int o = 32; o >= 1; o >>= 1) pk += __shfl_xor(pk, o, 64);
+                        if (lane == 0) s_ab[wave] = pk;                              // summed over the wavefronts at the publish
                     }
                 }
+                lds_barrier();
             }
-            lds_barrier();
         }
-        // work split: nt tiles of 16 markers; the 4 wavefronts = tsplit tile groups x ksplit parts of the slice
-        const int nt = (nb + 15) >> 4;
-        const int tsplit = nt >= 4 ? 4 : (nt >= 2 ? 2 : 1);
-        const int ksplit = 4 / tsplit;
-        const int wt = wave & (tsplit - 1), wk = wave / tsplit;
-        const int ss_lo = wk * (SS / ksplit);               // first super-step of this wavefront's part of the slice
-        const int mrow = lane & 15, kg = lane >> 4;
+        // ---- the tile passes: tile T of the batch goes to wavefront T & 3, two tiles (T and T + 4) per pass where there are two
         // operand B: columns 0..6 = the digit planes, 8 and 9 = the planes of the markers the walk may cross; the others
         // (7, 10..15) read plane 0 and their results are dropped
         const int ncol = lane & 15;
-        const int poff = ncol < 7 ? ncol * PST + (ncol >> 2) * 64 : ((ncol == 8 || ncol == 9) ? (ncol - 1) * PST + 64 : 0);
-        const char* pbase = planes + poff + kg * 64;
+        const int poff = ncol < 7 ? ncol * PST + (ncol >> 2) * 64 : ((CONT && (ncol == 8 || ncol == 9)) ? (ncol - 1) * PST + 64 : 0);
+        const uint32_t pb0 = lds_addr(planes + poff + kg * 64);
         constexpr uint32_t M0 = 0x03030303u, M1 = 0x01010101u;
-        // One pass = ONE or TWO tiles of 16 markers (t and t + tsplit: operand B is read once for both) x NS
-        // super-steps of the slice starting at ss_lo.  NS and the tile count are compile-time so that the body is
-        // ONE basic block; the LDS reads of super-step s + 1 are in flight during the arithmetic of s.
-        auto tile_pass = [&](auto ns_tag, auto nt_tag, auto fast_tag, int t) {
-            constexpr int NS = decltype(ns_tag)::value;
-            constexpr int NTL = decltype(nt_tag)::value;              // tiles in this pass
+        // One pass = ONE or TWO tiles of 16 markers x SS super-steps of the slice; operand B is read once for both.  KR >= 0: the
+        // first tile (tR) is register slot KR of this wavefront; NLD LDS-home tiles (tL0, tL1) follow.  All compile-time, so that the
+        // body is ONE basic block; the LDS reads of super-step s + 1 are in flight during the arithmetic of s.
+        auto tile_pass = [&](auto kr_tag, auto nld_tag, auto fast_tag, int tR, int tL0, int tL1) __attribute__((always_inline))  {
+            constexpr int KR = decltype(kr_tag)::value;
+            constexpr int NLD = decltype(nld_tag)::value;
+            constexpr int HR = KR >= 0 ? 1 : 0;
+            constexpr int NTL = HR + NLD;                             // tiles in this pass
             constexpr bool TF = decltype(fast_tag)::value;            // this batch's layout: no missing genotypes
-            uint32_t sl0[NTL];
-            int swz[NTL];
+            static_assert(NTL >= 1 && NTL <= 2, "tiles per pass");
+            int tq[NTL];
+            if constexpr (HR) tq[0] = tR;
+            if constexpr (NLD >= 1) tq[HR] = tL0;
+            if constexpr (NLD == 2) tq[1] = tL1;
+            uint32_t sl0[2] = {0u, 0u};
+            int swz[2] = {0, 0};
 #pragma unroll
-            for (int q = 0; q < NTL; q++) {
-                const int mk = 16 * (t + q * tsplit) + mrow;
-                const int pl = p0 + (mk < nb ? mk : nb - 1);          // idle rows shadow the last marker (their sums are dropped)
-                sl0[q] = lds_addr(ring + (size_t)rmod(pl) * SB);
+            for (int q = 0; q < NLD; q++) {
+                const int pl = 16 * tq[HR + q] + mrow;
+                sl0[q] = lds_addr(ring) + (uint32_t)lds_slot(tq[HR + q]) * (uint32_t)TILE_B + (uint32_t)mrow * (uint32_t)SB;
                 swz[q] = pl & (CPP - 1);
             }
-            const uint32_t pb0 = lds_addr(pbase) + (uint32_t)ss_lo * 256u;
             v4i acc0[NTL], acc1[NTL], acc2[NTL], zcc0[NTL], zcc1[NTL], zcc2[NTL];   // zcc: general layout, the missing-genotype indicator
 #pragma unroll
             for (int q = 0; q < NTL; q++) {
                 acc0[q] = v4i{0, 0, 0, 0}; acc1[q] = v4i{0, 0, 0, 0}; acc2[q] = v4i{0, 0, 0, 0};
                 zcc0[q] = v4i{0, 0, 0, 0}; zcc1[q] = v4i{0, 0, 0, 0}; zcc2[q] = v4i{0, 0, 0, 0};
             }
-            auto waddr = [&](int q, int s) { return sl0[q] + 16u * (uint32_t)((4 * (ss_lo + s) + kg) ^ swz[q]); };
-            Stage<NTL> stg[2];
-            stg[0] = stage_read<NTL>(pb0, waddr(0, 0), waddr(NTL - 1, 0));
+            auto waddr = [&](int q, int s2) __attribute__((always_inline))  { return sl0[q] + 16u * (uint32_t)((4 * s2 + kg) ^ swz[q]); };
+            Stage<NLD> stg[2];
+            stg[0] = stage_read<NLD>(pb0, waddr(0, 0), waddr(1, 0));
 #pragma unroll
-            for (int s = 0; s < NS; s++) {
-                if (s + 1 < NS) {
-                    stg[(s + 1) & 1] = stage_read<NTL>(pb0 + (uint32_t)(s + 1) * 256u, waddr(0, s + 1), waddr(NTL - 1, s + 1));
-                    stg[s & 1] = stage_wait<NTL, true>(stg[s & 1]);
+            for (int s2 = 0; s2 < SS; s2++) {
+                if (s2 + 1 < SS) {
+                    stg[(s2 + 1) & 1] = stage_read<NLD>(pb0 + (uint32_t)(s2 + 1) * 256u, waddr(0, s2 + 1), waddr(1, s2 + 1));
+                    stg[s2 & 1] = stage_wait<NLD, true>(stg[s2 & 1]);
                 } else {
-                    stg[s & 1] = stage_wait<NTL, false>(stg[s & 1]);
+                    stg[s2 & 1] = stage_wait<NLD, false>(stg[s2 & 1]);
                 }
-                const v4i b0 = stg[s & 1].b0, b1 = stg[s & 1].b1, b2 = stg[s & 1].b2, b3 = stg[s & 1].b3;
+                const v4i b0 = stg[s2 & 1].b0, b1 = stg[s2 & 1].b1, b2 = stg[s2 & 1].b2, b3 = stg[s2 & 1].b3;
 #pragma unroll
                 for (int q = 0; q < NTL; q++) {
-                    const u32x4 w = stg[s & 1].w[q];
+                    u32x4 w;
+                    if constexpr (HR) {
+                        if (q == 0) {
+                            // (pinned behind this super-step's wait: hipcc otherwise forms the field masks of ALL super-steps of a
+                            //  register tile up front -- the data is "there" -- and spills half the register file around them)
+                            w = rt[KR < 0 ? 0 : KR][s2];
+                            asm volatile("" : "+v"(w));
+                        } else w = stg[s2 & 1].w[q - HR];
+                    } else w = stg[s2 & 1].w[q];
                     const v4i a0 = {(int)(w.x & M0), (int)(w.y & M0), (int)(w.z & M0), (int)(w.w & M0)};
                     const v4i a1 = {(int)(w.x & (M0 << 2)), (int)(w.y & (M0 << 2)), (int)(w.z & (M0 << 2)), (int)(w.w & (M0 << 2))};
                     const v4i a2 = {(int)(w.x & (M0 << 4)), (int)(w.y & (M0 << 4)), (int)(w.z & (M0 << 4)), (int)(w.w & (M0 << 4))};
@@ -1605,97 +1760,127 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 #ifdef GM_PA_SPLIT
             PA(1);   // (diagnostic: "scan + inputs" then also holds the MFMA loop, "tiles" only the tile output)
 #endif
-            // C: column n = lane & 15 (digit plane), rows 4 kg + r (marker of the tile).  The four planes of
-            // one exact part meet in a quad: sum_p digit_p * 256^p as a 64-bit integer; the parts of the slice
-            // (ksplit wavefronts) meet in LDS (integer: exact, any order).
+            // C: column n = lane & 15 (digit plane), rows 4 kg + r (marker of the tile).  The planes of one exact part meet in a
+            // quad: planes n, n + 1 as an int32 pair (|sum| <= 2^20 per plane and slice: x + 256 x' fits), the two pairs as a 64-bit
+            // integer sum_p digit_p * 256^p.  The tile has ONE owner, so the sums are stored, not added: no LDS atomics, nothing to zero.
             const int n = lane & 15;
+            auto planes_sum = [&](int x) __attribute__((always_inline)) -> long long {                 // valid in the lanes with (n & 3) == 0
+                const int y = x + (__builtin_amdgcn_update_dpp(0, x, DPP_QUAD_1032, 0xf, 0xf, false) << 8);
+                const int y2 = __builtin_amdgcn_update_dpp(0, y, 0x4E, 0xf, 0xf, false);      // lane ^ 2
+                return (long long)y + ((long long)y2 << 16);
+            };
 #pragma unroll
             for (int q = 0; q < NTL; q++) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const int m = 16 * (t + q * tsplit) + 4 * kg + r;
-                    const int xr = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);  // sum c' * digit (c' = a wherever the residual is not 0)
+                    const int m = 16 * tq[q] + 4 * kg + r - p0;                      // batch position of this row
+                    const bool in = (unsigned)m < (unsigned)nb;
+                    const int xr = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);  // sum c * digit (c = a wherever the residual is not 0)
                     // columns 0..6: the digits of the two exact parts (the second has three: column 7 is not a plane)
-                    const int x = n == 7 ? 0 : xr;
-                    const long long sx = quad_sum64((long long)x << (8 * (n & 3)));
+                    const long long sx = planes_sum(n == 7 ? 0 : xr);
                     if (TF) {
-                        if ((n & 3) == 0 && n < 8 && m < nb) atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)sx);
+                        if ((n & 3) == 0 && n < 8 && in) s_sum[2 * m + (n >> 2)] = sx;
                     } else {
-                        // a = c' - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
-                        // slice's sum of d is added at the publish.  (A clean marker in this tile has Z = 0: code 11
+                        // a = c - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
+                        // slice's sum of d is added at the publish.  (A clean marker in this tile has Z = 0: code 3
                         // occurs for it only where the residual is 0.)
                         const int zr = zcc0[q][r] + (zcc1[q][r] >> 2) + (zcc2[q][r] >> 4);
-                        const int z = n == 7 ? 0 : zr;
-                        const long long sz = quad_sum64((long long)z << (8 * (n & 3)));
-                        if ((n & 3) == 0 && n < 8 && m < nb) {
-                            atomicAdd(&s_sum[2 * m + (n >> 2)], (unsigned long long)(sx - 3 * sz));
+                        const long long sz = planes_sum(n == 7 ? 0 : zr);
+                        if ((n & 3) == 0 && n < 8 && in) {
+                            s_sum[2 * m + (n >> 2)] = sx - 3 * sz;
                             if (all_dirty || dirty_at(dm0, dm1, m))
-                                atomicAdd(&s_sum[2 * nb + 2 + 2 * (all_dirty ? m : dirty_rank(dm0, dm1, m)) + (n >> 2)], (unsigned long long)(-sz));
+                                s_sum[2 * nb + 2 + 2 * (all_dirty ? m : dirty_rank(dm0, dm1, m)) + (n >> 2)] = -sz;
                         }
                     }
-                }
-            }
-            // columns 8, 9: G = sum a_j a_s over the slice for the markers s the walk may cross, kept for the markers behind s
-            // only and packed 24 bits apart in one slot (G < 2^24 over all individuals)
-            if (CONT && ns > 0) {                      // (uniform)
-#pragma unroll
-                for (int q = 0; q < NTL; q++) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int m = 16 * (t + q * tsplit) + 4 * kg + r;
-                        const int xr = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);
-                        if constexpr (CK == 1) {
-                            if (n == 8 && m > ps0 && m < nb) atomicAdd(&s_sum[2 * nb + 2 + m - ps0 - 1], (unsigned long long)xr);
-                            if (n == 9 && ns > 1 && m > ps1 && m < nb) atomicAdd(&s_sum[2 * nb + 2 + m - ps0 - 1], (unsigned long long)xr << 24);
-                        } else if constexpr (!TF) {
-                            // all-dirty layout: column 8 = a_s, column 9 = b_s of the one stop; per marker behind it
-                            //   slot 0: G_a | G_ab << 26 = sum a_j a_s | sum a_j b_s  (a_j = c' - 3 [missing]: X - 3 Z)
-                            //   slot 1: Z_a | Z_b << 26  = sum [j missing] a_s | sum [j missing] b_s
-                            const int zr = zcc0[q][r] + (zcc1[q][r] >> 2) + (zcc2[q][r] >> 4);
-                            if ((n == 8 || n == 9) && m > ps0 && m < nb) {
-                                const int sl = 4 * nb + 4 + 2 * (m - ps0 - 1);
-                                const int sh = n == 9 ? 26 : 0;
-                                atomicAdd(&s_sum[sl], (unsigned long long)(long long)(xr - 3 * zr) << sh);
-                                atomicAdd(&s_sum[sl + 1], (unsigned long long)(long long)zr << sh);
+                    // columns 8, 9: G = sum a_j a_s over the slice for the markers s the walk may cross, kept for the markers behind s
+                    // only and packed in one slot (column 9 comes to lane 8 through the quad)
+                    if constexpr (CONT) {
+                        if (ns > 0) {                  // (uniform)
+                            if constexpr (CK == 1) {
+                                const int x9 = __builtin_amdgcn_update_dpp(0, xr, DPP_QUAD_1032, 0xf, 0xf, false);
+                                if (n == 8 && m > ps0 && m < nb)
+                                    s_sum[2 * nb + 2 + m - ps0 - 1] = (long long)xr + ((ns > 1 && m > ps1) ? ((long long)x9 << 24) : 0ll);
+                            } else if constexpr (!TF) {
+                                // all-dirty layout: column 8 = a_s, column 9 = b_s of the one stop; per marker behind it
+                                //   slot 0: G_a | G_ab << 26 = sum a_j a_s | sum a_j b_s  (a_j = c - 3 [missing]: X - 3 Z)
+                                //   slot 1: Z_a | Z_b << 26  = sum [j missing] a_s | sum [j missing] b_s
+                                const int zr = zcc0[q][r] + (zcc1[q][r] >> 2) + (zcc2[q][r] >> 4);
+                                const int ga = xr - 3 * zr;
+                                const int ga9 = __builtin_amdgcn_update_dpp(0, ga, DPP_QUAD_1032, 0xf, 0xf, false);
+                                const int zr9 = __builtin_amdgcn_update_dpp(0, zr, DPP_QUAD_1032, 0xf, 0xf, false);
+                                if (n == 8 && m > ps0 && m < nb) {
+                                    const int sl = 4 * nb + 4 + 2 * (m - ps0 - 1);
+                                    s_sum[sl] = (long long)ga + ((long long)ga9 << 26);
+                                    s_sum[sl + 1] = (long long)zr + ((long long)zr9 << 26);
+                                }
                             }
                         }
                     }
                 }
             }
         };
+        using ICm1 = std::integral_constant<int, -1>;
+        using IC0 = std::integral_constant<int, 0>;
         using IC1 = std::integral_constant<int, 1>;
         using IC2 = std::integral_constant<int, 2>;
-        // the 16 positions of tile t hold a dirty marker?  (tiles 0..3: dm0, 4..7: dm1)
-        auto tile_dirty = [&](int t) { return !sparse_z && (((t < 4 ? dm0 >> (16 * t) : dm1 >> (16 * (t - 4))) & 0xffffull) != 0ull); };
-        auto one_pass = [&](auto ns_tag, auto nt_tag, int t, bool dirty) {
-            if constexpr (MODE == 0) tile_pass(ns_tag, nt_tag, std::true_type{}, t);
-            else if constexpr (MODE == 2) tile_pass(ns_tag, nt_tag, std::false_type{}, t);
-            else { if (dirty) tile_pass(ns_tag, nt_tag, std::false_type{}, t); else tile_pass(ns_tag, nt_tag, std::true_type{}, t); }
+        // the 16 positions of tile t hold a dirty marker?  (batch positions 0..127: dm0, dm1)
+        auto tile_dirty = [&](int t) __attribute__((always_inline)) -> bool {
+            if (MODE != 1) return MODE == 2;
+            if (sparse_z) return false;
+            int lo = 16 * t - p0, hi = lo + 16;       // batch positions of the tile's rows
+            if (lo < 0) lo = 0;
+            if (hi > 128) hi = 128;
+            bool d = false;
+            for (int m = lo; m < hi; m++) d |= dirty_at(dm0, dm1, m);
+            return d;
         };
-        if (ksplit == 1) {                            // four or more tiles: every wavefront walks whole slices, two tiles at a time
+        auto one_pass = [&](auto kr_tag, auto nld_tag, int tR, int tL0, int tL1, bool dirty) __attribute__((always_inline))  {
+            if constexpr (MODE == 0) tile_pass(kr_tag, nld_tag, std::true_type{}, tR, tL0, tL1);
+            else if constexpr (MODE == 2) tile_pass(kr_tag, nld_tag, std::false_type{}, tR, tL0, tL1);
+            else { if (dirty) tile_pass(kr_tag, nld_tag, std::false_type{}, tR, tL0, tL1); else tile_pass(kr_tag, nld_tag, std::true_type{}, tR, tL0, tL1); }
+        };
+        {
+            const int tb0 = p0 >> 4, tb1 = (p0 + nb - 1) >> 4;          // tiles of the batch
+            int t = tb0 + ((wave - tb0) & 3);                           // this wavefront's first: t & 3 == wave
 #pragma unroll 1
-            for (int t = wt; t < nt; t += 8) {
-                if (t + 4 < nt) one_pass(std::integral_constant<int, SS>{}, IC2{}, t, tile_dirty(t) || tile_dirty(t + 4));   // tiles t and t + 4 share operand B
-                else one_pass(std::integral_constant<int, SS>{}, IC1{}, t, tile_dirty(t));
-            }
-        } else {                                      // fewer tiles than wavefronts: the slice is split ksplit ways
-#pragma unroll 1
-            for (int t = wt; t < nt; t += tsplit) {
-                if (ksplit == 2) one_pass(std::integral_constant<int, SS / 2>{}, IC1{}, t, tile_dirty(t));
-                else one_pass(std::integral_constant<int, SS / 4>{}, IC1{}, t, tile_dirty(t));
+            for (; t <= tb1; t += 8) {
+                const bool two = t + 4 <= tb1;
+                const bool reg0 = is_reg(t), reg1 = two && is_reg(t + 4);   // (at most one of a pair lives in registers: T & 7 and (T + 4) & 7)
+                if (!reg0 && !reg1) {
+                    if (two) one_pass(ICm1{}, IC2{}, 0, t, t + 4, tile_dirty(t) || tile_dirty(t + 4));
+                    else one_pass(ICm1{}, IC1{}, 0, t, 0, tile_dirty(t));
+                } else if constexpr (NP > 0) {
+                    const int tr = reg0 ? t : t + 4, tl = reg0 ? t + 4 : t;
+                    const int k = reg_slot(tr);
+                    const bool dirty = tile_dirty(t) || (two && tile_dirty(t + 4));
+                    auto go = [&](auto k_tag) __attribute__((always_inline))  {
+                        if (two) one_pass(k_tag, IC1{}, tr, tl, 0, dirty);
+                        else one_pass(k_tag, IC0{}, tr, 0, 0, dirty);
+                    };
+                    if (k == 0) go(IC0{});
+                    if constexpr (NP > 1) { if (k == 1) go(IC1{}); }
+                    if constexpr (NP > 2) { if (k == 2) go(IC2{}); }
+                }
             }
         }
         PA(2);
-        lds_barrier();                                // the LDS sums are complete (prefetches stay in flight)
+        lds_barrier();                                // the LDS sums are complete (tile loads stay in flight)
         PA(3);
         const int nv0 = 2 * nb + 2 + 2 * nd;
         // behind a crossed stop: one more value per marker (two, and two for the stop, in the all-dirty layout)
         const int nv = nv0 + ((CONT && ns > 0) ? (CK == 2 ? 2 + 2 * (nb - 1 - ps0) : nb - 1 - ps0) : 0);
-        if (CONT && ns > 0) {                       // (uniform) packed G counts: integers < 2^48, exact as doubles
-            for (int vi = nv0 + tid; vi < nv; vi += SW_TPB) {
-                const double tot = (double)(long long)s_sum[vi];
-                s_sum[vi] = 0ull;
-                put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)vi * a.Wpad + wg), b.gen + 1u, tot);
+        if constexpr (CONT) {
+            if (ns > 0) {                             // (uniform) packed G counts: integers < 2^52, exact as doubles
+                for (int vi = nv0 + tid; vi < nv; vi += SW_TPB) {
+                    long long v = s_sum[vi];
+                    if constexpr (CK == 2) {          // the stop's own sums A_s, B_s: the wavefronts' shares of the plane build
+                        if (vi < nv0 + 2) {
+                            const int sh = vi == nv0 ? 0 : 16;
+                            v = ((s_ab[0] >> sh) & 0xFFFF) + ((s_ab[1] >> sh) & 0xFFFF) + ((s_ab[2] >> sh) & 0xFFFF) + ((s_ab[3] >> sh) & 0xFFFF);
+                        }
+                    }
+                    put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)vi * a.Wpad + wg), b.gen + 1u, (double)v);
+                }
             }
         }
         for (int vi = tid; vi < nv0; vi += SW_TPB) {          // up to SW_VMAX values, 256 threads
@@ -1704,10 +1889,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 const int w2 = vi - 2 * nb;
                 tot = s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2];
             } else {
-                long long v = (long long)s_sum[vi];
+                long long v = s_sum[vi];
                 if constexpr (MODE == 1) {
                     if (sparse_z) {                   // X - 3 Z for the a-sums of a dirty marker, -Z in its own b-slots
-                        if (vi >= 2 * nb + 2) v -= s_zsp[vi - (2 * nb + 2)];
+                        if (vi >= 2 * nb + 2) v = -s_zsp[vi - (2 * nb + 2)];
                         else if (dirty_at(dm0, dm1, vi >> 1)) v -= 3 * s_zsp[2 * dirty_rank(dm0, dm1, vi >> 1) + (vi & 1)];
                     }
                 }
@@ -1718,7 +1903,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 }
                 // |sum| < 2^53 grid units: the conversion and the power-of-two scaling are exact
                 tot = (double)v * ((vi & 1) ? GRID : 0x1p-22);
-                s_sum[vi] = 0ull;
             }
             put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)vi * a.Wpad + wg), b.gen + 1u, tot);
         }
@@ -1727,7 +1911,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     };
 
     // reduce role: workgroup v sums row v of generation b.gen over all workgroups
-    auto reduce_role = [&](const Batch& b) -> bool {
+    auto reduce_role = [&](const Batch& b) __attribute__((always_inline)) -> bool {
         bool bad = false;
         if (wg < b.nv) {
             const unsigned long long* Pb = Pg + 2 * (size_t)(b.gen & 1u) * SW_VMAX * a.Wpad;
@@ -1751,8 +1935,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 if (tid == 0) put_value(Tb + 2 * v, b.gen + 1u, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
                 lds_barrier();
             } else if (rows == 2) {
-                // a batch with markers behind a crossed stop (or many dirty markers) has more rows than there are workgroups:
-                // rows wg and wg + W in one pass, both granules of a thread in flight together
+                // a long batch (or one with markers behind a crossed stop, or many dirty markers) has more rows than there are
+                // workgroups: rows wg and wg + W in one pass, both granules of a thread in flight together
                 double x0 = 0.0, x1 = 0.0;
                 if (tid < W) {
                     Spin sp;
@@ -1774,12 +1958,12 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 if (tid == 64) put_value(Tb + 2 * (wg + W), b.gen + 1u, s_red[4] + s_red[5] + s_red[6] + s_red[7]);
                 lds_barrier();
             } else {
-                // Fewer workgroups than rows (small N: 49 workgroups, up to 242 rows): all rows of this workgroup in ONE
+                // Fewer workgroups than rows (small N: 49 workgroups, up to 482 rows): all rows of this workgroup in ONE
                 // pass -- thread t waits for granules t, t + 256, ... of the rows x W it needs and adds each to its row's
                 // LDS accumulator (ds_add_f64; the values are exact, so the order does not matter).  One row after the
                 // other cost a memory round trip and two barriers per row.
                 double* s_rows = reinterpret_cast<double*>(smem + L_TOT);       // free until wavefront 0 polls the totals
-                if (tid < rows) s_rows[tid] = 0.0;
+                for (int r = tid; r < rows; r += SW_TPB) s_rows[r] = 0.0;
                 lds_barrier();
                 const int total = rows * W;
                 for (int g = tid; g < total; g += SW_TPB) {
@@ -1794,73 +1978,47 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     __hip_atomic_fetch_add(&s_rows[r], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 lds_barrier();
-                if (tid < rows) put_value(Tb + 2 * (wg + tid * W), b.gen + 1u, s_rows[tid]);
+                for (int r = tid; r < rows; r += SW_TPB) put_value(Tb + 2 * (wg + r * W), b.gen + 1u, s_rows[r]);
                 lds_barrier();
             }
         }
         return bad;
     };
 
-    Batch cur{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0}, nxt{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0}, tb{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0};
-    LaneIn li_cur0{0, 0, 0.0, 0.0, 1.0}, li_cur1{0, 0, 0.0, 0.0, 1.0}, li_nxt0{0, 0, 0.0, 0.0, 1.0}, li_nxt1{0, 0, 0.0, 0.0, 1.0};
+    Batch cur{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0};
+    LaneIn li_cur0{0, 0, 0.0, 0.0, 1.0}, li_cur1{0, 0, 0.0, 0.0, 1.0};
     bool bad = false;
-    {
-        const int first = RPOS < a.M ? RPOS : a.M;
-        fill(0, first);
-        hi = first;
-        ensure_meta(META_POS < a.M ? META_POS : a.M);
-        __syncthreads();
-    }
-    // One compute site and one reduce site serve the three cases (first batch, restart after a
-    // residual update, speculative next batch); `restart` / `need_reduce` select the case.
-    bool restart = true, need_reduce = false, have_next = false;
+    ensure_meta(META_POS < a.M ? META_POS : a.M);
+    __syncthreads();
     while (pos < a.M) {
-        TRACE(restart ? 0 : 7);
-        if (need_reduce) { bad = reduce_role(cur); need_reduce = false; TRACE(2); }
-        PROF(0);   // reduce role
-        bool do_compute = false;
-        if (restart) {
+        TRACE(0);
+        // ---- the batch: what the run-length estimate asks for, as far as tiles and sampling inputs are on chip
+        bool fill_round = false;                      // (uniform) nothing to walk yet: only request tiles (start-up; a walk that ran through a short window)
+        {
             int nb0 = ctl[C_NBNEXT];
             if (nb0 > a.M - pos) nb0 = a.M - pos;
-            tb.p0 = pos; tb.nb = nb0; tb.gen = gen_next++;
-            do_compute = true;
-        } else if (!cur.planned && ctl[C_EMA] >= a.spec_factor16 * cur.nb) {   // never behind a certain stop; else only when the recent run length (1/16 units)
-            const int p1 = pos + cur.nb;              // is long enough: P(no residual update) >~ 1/2
-            if (p1 < a.M) {
-                int nb1 = ctl[C_NBNEXT];
-                if (nb1 > a.M - p1) nb1 = a.M - p1;
-                if (nb1 > pos + RPOS - p1) nb1 = pos + RPOS - p1;   // both batches live in the ring
-                if (nb1 > 0) {
-                    tb.p0 = p1; tb.nb = nb1; tb.gen = gen_next++;
-                    do_compute = true;
-                }
-            }
+            int have = 16 * t_hi - pos;               // (tiles beyond the block's end do not exist: nb0 <= M - pos)
+            if (have < nb0 && have < 16) fill_round = true;
+            if (!fill_round && mhi - pos < 16 && mhi < a.M) ensure_meta(pos + 64 < a.M ? pos + 64 : a.M);   // (slow path; the refill keeps up in practice)
+            if (mhi - pos < have) have = mhi - pos;
+            if (have < nb0) { nb0 = have; n_short++; }
+            cur.p0 = pos; cur.nb = nb0; cur.gen = gen_next;
         }
-        if (do_compute) {
-            ensure(tb.p0 + tb.nb);
-            ensure_meta(tb.p0 + tb.nb);
-            // ONE inlined copy of phase A (instruction cache): the lane inputs land in temporaries first
-            LaneIn lt0{0, 0, 0.0, 0.0, 1.0}, lt1{0, 0, 0.0, 0.0, 1.0};
-            compute_publish(tb, lt0, lt1);
-            if (restart) { li_cur0 = lt0; li_cur1 = lt1; } else { li_nxt0 = lt0; li_nxt1 = lt1; }
+        if (fill_round) {
+            // ONE inlined copy of the tile loads serves start-up, this slow path and the steady state (below): more copies made the
+            // register allocator keep a slot's registers in different places at different sites, with copies of registers whose
+            // loads were in flight in between (tools/check_prefetch_regs.py)
+            n_short++;
         }
-        if (restart) TRACE(1);
-        PROF(1);   // dots + publish (restart: on the critical path; speculative: overlaps the exchange)
-        if (restart) {
-            cur = tb;
-            restart = false;
-            need_reduce = true;
-            continue;
-        }
-        have_next = do_compute;
-        if (have_next) nxt = tb;
-        // The sampled batch of the PREVIOUS round has released its ring slots: recode and park what was requested
-        // during that round (wavefronts 1-3; wavefront 0 is on its way to the totals), then request the
-        // slices / sampling inputs the ring can take once the current batch has been walked to its end.
-        // The loader wavefronts idle through the exchange and the sampling step, which hides the recoding,
-        // the marker-id round trip and most of the HBM latency.
-        prefetch_commit();
-        PROF(3);   // recode + ring write of the previous round's prefetch
+        tiles_wait();                                 // the tiles requested a round ago are there (no wait in practice)
+        if (!fill_round) {
+        gen_next++;
+        compute_publish(cur, li_cur0, li_cur1);
+        TRACE(1);
+        PROF(1);   // dots + publish
+        bad = reduce_role(cur);
+        TRACE(2);
+        PROF(0);   // reduce role
 
         // ---- sampling step of the current batch (wavefront 0, every workgroup, identical inputs)
         if (wave == 0) {
@@ -1874,22 +2032,23 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             PROF(4);   // wait for the totals
             bad |= !okw;
             if (okw) {
+                const int mpos0 = cur.p0 & (META_POS - 1);
                 // the tables are read through a pointer of known address space (LDS)
-                auto run_step = [&](auto tabq) {
+                auto run_step = [&](auto tabq) __attribute__((always_inline))  {
                     if (K == 4) {
-                        sample_batch_body<4, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, draws, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1);
+                        sample_batch_body<4, CK, LONGB>(cur.nb, mpos0, BCAP, a.nb_factor16, G, smem, tabq, li_cur0, li_cur1, tot0, tot1, draws, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1);
                     } else {
                         // out-of-line copies take their inputs by address: hand them copies, so that the
                         // loop-carried lane inputs themselves stay in registers (no scratch round trips)
                         const LaneIn lc0 = li_cur0, lc1 = li_cur1;
                         const Totals tc0 = tot0, tc1 = tot1;
                         switch (K) {
-                            case 2: sample_batch<2, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 3: sample_batch<3, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 5: sample_batch<5, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 6: sample_batch<6, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            case 7: sample_batch<7, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
-                            default: sample_batch<8, CK>(cur.nb, BMAX, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 2: sample_batch<2, CK, LONGB>(cur.nb, mpos0, BCAP, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 3: sample_batch<3, CK, LONGB>(cur.nb, mpos0, BCAP, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 5: sample_batch<5, CK, LONGB>(cur.nb, mpos0, BCAP, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 6: sample_batch<6, CK, LONGB>(cur.nb, mpos0, BCAP, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            case 7: sample_batch<7, CK, LONGB>(cur.nb, mpos0, BCAP, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
+                            default: sample_batch<8, CK, LONGB>(cur.nb, mpos0, BCAP, a.nb_factor16, G, smem, tabq, lc0, lc1, tc0, tc1, draws.p0, draws.p1, a.sigmae, a.inv2sige, a.nm1, so, wg == 0, a.lds_cass, cur.ns, cur.ps0, cur.ps1); break;
                         }
                     }
                 };
@@ -1897,21 +2056,27 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             }
         }
         PROF(7);   // sampling step (wavefront 0's own time)
-        // request the slices / sampling inputs the ring can take once the current batch has been walked to its
-        // end.  Wavefronts 1-3 get here at once (they skip the block above) and issue while wavefront 0 samples;
-        // the column loads wait for the totals (gate inside).
-        meta_ids(pos + cur.nb + META_POS);
-        prefetch_issue(pos + ((cur.nb * a.pf_ahead16) >> 4) + RPOS, cur.gen + 1u, true);
-        PROF(2);   // prefetch issue
+        }   // !fill_round
+        // The walk before this one has released tiles and sampling inputs: request what the window and the meta ring can take
+        // now.  Wavefronts 1-3 get here at once (they skip the block above) and issue while wavefront 0 samples; the tile loads
+        // wait for the totals (gate inside).  What is requested here is used from the NEXT round on.
+        meta_ids(fill_round ? 0 : pos + META_POS + cur.nb);
+        {
+            int t_lim = (pos >> 4) + WIN;
+            if (t_lim > ntiles) t_lim = ntiles;
+            tile_issue(t_lim, fill_round ? 0u : cur.gen + 1u, !fill_round);
+        }
+        PROF(2);   // tile / meta requests
+        if (fill_round) { lds_barrier(); continue; }  // (the loads are waited for at the top of the next round)
         if (bad) ctl[C_BAD] = 1;
-        lds_barrier();                                // no vmcnt drain: prefetches stay in flight
+        lds_barrier();                                // (tile loads stay in flight)
         if (ctl[C_BAD] || ctl[C_RNGERR] || ctl[C_RANGE]) { ok = false; break; }
         TRACE(5);
         PROF(5);   // barrier after sampling
 
-        // ---- phase C: residual update of the stopping marker (its slice is in the ring) ----
+        // ---- phase C: residual updates of the round (the markers the walk crossed and the one it stopped at) ----
         const int n_done = ctl[C_NDONE];
-        const int nupd = ctl[C_UPD];                  // residual updates of this round: the markers the walk crossed and the one it stopped at
+        const int nupd = ctl[C_UPD];
         const bool upd = nupd != 0;
         n_planned += ctl[C_PLN];
         n_cross += ctl[C_SUPD];
@@ -1920,12 +2085,14 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (upd) {
             n_upd += nupd;
             const UpdList ul = upd_list(smem);
+            if (stage_slices(nupd, [&](int u) __attribute__((always_inline))  { return pos + ul.pos[u]; })) lds_barrier();      // register-home markers: their owners hand the slices over
 #pragma unroll 1
             for (int u = 0; u < nupd; u++) {
                 const int ps = pos + ul.pos[u];
                 const double* uv = ul.val + 4 * u;
-                // this thread's ND dwords of the slice: field o_fld of each byte is one of its individuals (ring codes c')
-                const char* own = ring + (size_t)rmod(ps) * SB + 16 * (o_chunk ^ (ps & (CPP - 1))) + o_jb;
+                // this thread's ND dwords of the slice: field o_fld of each byte is one of its individuals (device codes)
+                const SliceAt sa = slice_at(ps, u);
+                const char* own = sa.base + 16 * (o_chunk ^ sa.swz) + o_jb;
 #pragma unroll
                 for (int d = 0; d < ND; d++) {
                     const uint32_t cd = (*reinterpret_cast<const uint32_t*>(own + 4 * d) | na_or[d]) >> (2 * o_fld);
@@ -1939,18 +2106,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         n_batch++;
         TRACE(6);
         PROF(6);   // residual update + plane refresh
-        const bool will_restart = upd || n_done < cur.nb || !have_next;
         meta_commit();
         if (ctl[C_CURSOR] >= 624) block_advance(s_rng0, s_rng1, ctl, true);
-        if (will_restart) {                           // the speculative batch (if any) is stale: restart
-            if (have_next) n_disc++;
-            restart = true;
-        } else {                                      // promote: its partials are already at the reducers
-            cur = nxt;
-            li_cur0 = li_nxt0; li_cur1 = li_nxt1;
-            need_reduce = true;
-        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may be in flight when the workgroup ends
 
     if (ok) {                                         // a range violation in the last update is seen here
         __syncthreads();
@@ -1974,7 +2133,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         for (int i = tid; i < 624; i += SW_TPB) a.rng_state[i] = s_rng0[i];
         if (tid == 0) {
             *a.rng_index = ctl[C_CURSOR];
-            a.stats[0] = n_upd; a.stats[1] = n_batch; a.stats[2] = max_nb; a.stats[3] = n_disc;
+            a.stats[0] = n_upd; a.stats[1] = n_batch; a.stats[2] = max_nb; a.stats[3] = n_short;
             a.stats[29] = n_planned; a.stats[30] = n_stale; a.stats[31] = n_fastb; a.stats[32] = n_cross;
             a.stats[33] = ctl[C_NSCRT]; a.stats[34] = ctl[C_NSCR];
         }
@@ -2000,16 +2159,21 @@ int sweep_pick_R(size_t stride, int max_wg, int* W_out) {
 }
 
 template <int R, int MODE, bool CONT> static hipError_t launch_RF(const SweepArgs& a0, hipStream_t st, int grid) {
-    const int lds = lds_total<R>();
+    const int lds = L_TOTAL;
     SweepArgs a = a0;
-    const Carve cv = carve_for<R>(a.G, a.K);
-    a.lds_cass = cv.cass; a.lds_tab = cv.tab; a.lds_pln = cv.pln; a.lds_ring = cv.ring; a.rpos = cv.rpos; a.rpos_magic = cv.magic;
-    if (cv.rpos < 32) return hipErrorInvalidValue;
+    const Carve cv = carve_for<R, CONT>(a.G, a.K);
+    a.lds_cass = cv.cass; a.lds_tab = cv.tab; a.lds_pln = cv.pln; a.lds_ring = cv.ring; a.nl = cv.nl; a.nl_magic = cv.nl_magic; a.win = cv.win;
+    if (cv.win < 4) return hipErrorInvalidValue;     // (cannot happen for G <= 64, K <= 8: the tables leave room for several tiles)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, MODE, CONT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_sweep<R, MODE, CONT>), dim3(grid), dim3(SW_TPB), lds, st, a);
     return hipGetLastError();
 }
+#ifdef GM_ONE_KERNEL
+// experiments on code generation (tools/one_kernel.sh): only k_sweep<2, 0, false> is instantiated -- not a product build
+hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) { return launch_RF<2, 0, false>(a, st, grid); }
+hipError_t sweep_occupancy(int, int* blocks_per_cu) { *blocks_per_cu = 1; return hipSuccess; }
+#else
 template <int R> static hipError_t launch_R(const SweepArgs& a, hipStream_t st, int grid) {
     switch (a.miss_mode) {
         case 0: return a.cross > 0 ? launch_RF<R, 0, true>(a, st, grid) : launch_RF<R, 0, false>(a, st, grid);
@@ -2033,7 +2197,7 @@ hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) {
 // layouts' answers): the kernel's workgroups wait for each other, so a launch is only legal when the
 // whole grid is resident.  The LDS request (> 80 KiB) makes this 1.
 template <int R> static hipError_t occupancy_R(int* out) {
-    const int lds = lds_total<R>();
+    const int lds = L_TOTAL;
     int n0 = 0, n1 = 0;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
@@ -2054,5 +2218,6 @@ hipError_t sweep_occupancy(int R, int* blocks_per_cu) {
         default: return hipErrorInvalidValue;
     }
 }
+#endif
 
 }  // namespace gm

@@ -142,10 +142,10 @@ def check_stage(name, lines):
 
 
 def check_kernel(name, lines):
-    """Forward data-flow over the kernel's basic blocks.  State = "every asm prefetch load issued so far has
-    landed": cleared by an asm `global_load_dwordx4 a[..]`, set by any `s_waitcnt` with vmcnt(0) (the
-    hardware counter covers asm loads too).  Every other instruction that names a prefetch AGPR must see
-    the state set on EVERY path that reaches it."""
+    """Forward data-flow over the kernel's basic blocks, per register (round 4: the register-home tiles are loaded slot by
+    slot while the other slots are in use).  State = the AGPRs named by an asm `global_load_dwordx4 a[..]` since the last
+    `s_waitcnt` with vmcnt(0) on ANY path (the hardware counter covers asm loads too).  No other instruction may name a
+    register in that set -- not a read, not a copy, not a spill, not a second load."""
     pf = set()
     for ln in lines:
         s = ln.strip()
@@ -197,25 +197,33 @@ def check_kernel(name, lines):
             pred[j].append(i)
 
     def transfer(state, ins, report):
+        # state: the AGPRs named by an asm tile load since the last vmcnt(0) on some path (their data may not have landed)
+        state = set(state)
         for s in ins:
             if s.startswith("global_load_dwordx4 a["):
-                state = False
+                dst = agprs(s.split(",")[0])
+                again = dst & state
+                if again and report is not None:
+                    report.append(f"{name}: `{s}` loads into register(s) {sorted(again)[:4]}.. whose previous load may still be in flight")
+                state |= dst
                 continue
             if s.startswith("s_waitcnt") and "vmcnt(0)" in s:
-                state = True
+                state = set()
                 continue
-            touched = agprs(s) & pf
-            if touched and not state and report is not None:
-                report.append(f"{name}: `{s}` touches prefetch register(s) {sorted(touched)[:4]}.. while a prefetch load may still be in flight")
+            touched = agprs(s) & state
+            if touched and report is not None:
+                report.append(f"{name}: `{s}` touches tile register(s) {sorted(touched)[:4]}.. while their load may still be in flight")
         return state
 
     n = len(blocks)
-    inn = [True] * n                      # optimistic start, meet = AND
+    inn = [set() for _ in range(n)]        # start empty, meet = union (a register is pending if it is on ANY path)
     changed = True
     while changed:
         changed = False
         for i in range(n):
-            st = all(transfer(inn[j], blocks[j]["ins"], None) for j in pred[i]) if pred[i] else True
+            st = set()
+            for j in pred[i]:
+                st |= transfer(inn[j], blocks[j]["ins"], None)
             if st != inn[i]:
                 inn[i], changed = st, True
     problems = []
@@ -223,7 +231,7 @@ def check_kernel(name, lines):
         transfer(inn[i], blocks[i]["ins"], problems)
     if not problems:
         reads = sum(1 for b in blocks for s in b["ins"] if s.startswith("v_accvgpr_read_b32") and agprs(s) & pf)
-        print(f"ok  {name}: {len(pf)} prefetch AGPRs in {n} basic blocks; {reads} reads, all behind a vmcnt(0) wait on every path")
+        print(f"ok  {name}: {len(pf)} tile AGPRs in {n} basic blocks; {reads} reads, none of a register whose load may be in flight")
     return problems
 
 
