@@ -695,6 +695,9 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     const int first = in->count == 0 ? 0 : in->first, count = in->count == 0 ? c->M : in->count;
     if (in->count != 0 && (in->first < 0 || in->count < 0 || (long long)in->first + in->count > c->M))
         return fail(GMRM_EINVAL, "part of the sweep outside [0, M)");
+    if (count >= (1 << 24) - 2)
+        return fail(GMRM_EINVAL, "a sweep launch covers at most 16 777 213 markers (the exchange tags count the rounds of a launch modulo 2^24): "
+                                 "sweep a larger block in parts (gmrm_sweep_in.first / count, gmrm_sampler_launch_part)");
     if (first != tr.part_next && !(first == 0))
         return fail(GMRM_ESTATE, "parts of a sweep must be launched in order of position (expected first = " + std::to_string(tr.part_next) + ")");
     HIPCHK(hipSetDevice(c->device));

@@ -190,6 +190,30 @@ __device__ __forceinline__ void get_value2(const unsigned long long* g0, const u
     if (!ok0 && d0.y == tag && d0.w == tag) { ok0 = true; v0 = __longlong_as_double((long long)(((unsigned long long)d0.z << 32) | d0.x)); }
     if (!ok1 && d1.y == tag && d1.w == tag) { ok1 = true; v1 = __longlong_as_double((long long)(((unsigned long long)d1.z << 32) | d1.x)); }
 }
+// Packed partial sums (the long-batch kernel, round 4): BOTH exact parts of one marker's sum over ONE workgroup's slice in
+// a single 16-byte granule pair, so that a batch of 240 markers exchanges 241 rows instead of 482 (one row per reducer
+// workgroup, one store per publishing thread, as with batches of 120).  A slice's part on the 2^-22 grid is below 2^43 units
+// (|k| <= 2^30 per individual, 4096 individuals, a <= 2) and the rest below 2^34 units: 44 + 35 = 79 bits beside two 24-bit tags:
+//   granule 0 = {part1 bits 0..39, tag}     granule 1 = {part1 bits 40..43 | part2 << 4, tag}
+// (tags count the rounds of a launch modulo 2^24; gmrm_sweep_launch refuses launches of 2^24 markers or more.)
+__device__ __forceinline__ void put_packed(unsigned long long* g, unsigned tag24, long long p1, long long p2) {
+    const unsigned long long M40 = (1ull << 40) - 1ull;
+    const unsigned long long g0 = ((unsigned long long)p1 & M40) | ((unsigned long long)tag24 << 40);
+    const unsigned long long g1 = ((((unsigned long long)p1 >> 40) & 0xFull) | (((unsigned long long)p2 & ((1ull << 35) - 1ull)) << 4)) | ((unsigned long long)tag24 << 40);
+    const u32x4 d = {(unsigned)g0, (unsigned)(g0 >> 32), (unsigned)g1, (unsigned)(g1 >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(g), "v"(d) : "memory");
+}
+__device__ __forceinline__ bool get_packed(const unsigned long long* g, unsigned tag24, double& x1, double& x2) {
+    u32x4 d;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(d) : "v"(g) : "memory");
+    const unsigned long long g0 = ((unsigned long long)d.y << 32) | d.x, g1 = ((unsigned long long)d.w << 32) | d.z;
+    const unsigned long long M40 = (1ull << 40) - 1ull;
+    const long long p1 = (long long)(((g0 & M40) | ((g1 & 0xFull) << 40)) << 20) >> 20;       // sign-extend 44 bits
+    const long long p2 = (long long)(((g1 & M40) >> 4) << 29) >> 29;                           // sign-extend 35 bits
+    x1 = (double)p1; x2 = (double)p2;                                                          // exact (< 2^53)
+    return (unsigned)(g0 >> 40) == tag24 && (unsigned)(g1 >> 40) == tag24;
+}
+
 // lane l of a wavefront: values l, 64+l, 128+l, 192+l of one generation's totals in a single round trip
 __device__ __forceinline__ void get_row4(const unsigned long long* base, int lane, u32x4 (&d)[4]) {
     const unsigned long long* g = base + 2 * lane;
@@ -661,7 +685,7 @@ __device__ __forceinline__ void walk_piece(Walk& w, int nb, int mpos0, int G, ch
                 const double* mr_beta = reinterpret_cast<const double*>(mr_g + META_POS);
                 in = LaneIn{mr_m[sl], mr_g[sl], mr_beta[sl], mr_beta[META_POS + sl], mr_beta[2 * META_POS + sl]};
                 const double* s_tot = reinterpret_cast<const double*>(smem + L_TOT);
-                tt = Totals{s_tot[2 * pp], s_tot[2 * pp + 1], s_tot[2 * nb], s_tot[2 * nb + 1]};
+                tt = Totals{s_tot[pp], 0.0, s_tot[nb], 0.0};          // (the long-batch kernel exchanges one total per marker: poll_totals<true>)
             }
         }
         const bool act = lane < nbp && lane >= lo;
@@ -873,6 +897,7 @@ __device__ __forceinline__ bool dirty_at(unsigned long long dm0, unsigned long l
 // lines, one round trip per look, ~6x fewer requests to the one hot 4 KB region than per-marker
 // polling), parks them in LDS and lane j picks the values of batch positions j and 64 + j.
 // Returns false on timeout.
+template <bool PACKED>
 __device__ __forceinline__ bool poll_totals(int nb, int nv, unsigned long long dm0, unsigned long long dm1,
                                             const unsigned long long* Ttg, unsigned tag, char* smem,
                                             Totals& tot0, Totals& tot1, unsigned* abort_word, unsigned long long spin_limit) {
@@ -903,6 +928,13 @@ __device__ __forceinline__ bool poll_totals(int nb, int nv, unsigned long long d
     else if (nv <= 384) look(std::integral_constant<int, 6>{});
     else look(std::integral_constant<int, 8>{});
     Totals t0{0.0, 0.0, 0.0, 0.0}, t1{0.0, 0.0, 0.0, 0.0};
+    if constexpr (PACKED) {                      // one total per marker: the reducer has added the two exact parts already (one rounding)
+        const double sq = s_tot[nb];
+        if (lane < nb) t0 = Totals{s_tot[lane], 0.0, sq, 0.0};
+        if (lane + 64 < nb) t1 = Totals{s_tot[lane + 64], 0.0, sq, 0.0};
+        tot0 = t0; tot1 = t1;
+        return !__any(bad);
+    }
     const double sq1 = s_tot[2 * nb], sq2 = s_tot[2 * nb + 1];
     if ((dm0 | dm1) == 0ull) {                   // (uniform) the usual case: no dirty marker in the batch
         if (lane < nb) t0 = Totals{s_tot[2 * lane], s_tot[2 * lane + 1], sq1, sq2};
@@ -1222,15 +1254,24 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
 
     // one LDS tile: GPT wave-instructions of 1 KiB; lane l of instruction i: chunk slot l % CPP of position i * PPG + l / CPP,
     // the XOR swizzle applied on the source side
-    auto load_lds_tile = [&](int T, int idl) __attribute__((always_inline))  {        // idl: lane l holds the marker id of position 16 T + (l & 15)
+    auto load_lds_tile = [&](int T, int idl) __attribute__((always_inline)) {        // idl: lane l holds the marker id of position 16 T + (l & 15)
         const uint32_t dst0 = lds_addr(ring) + (uint32_t)lds_slot(T) * (uint32_t)TILE_B;
         const int cs = lane & (CPP - 1), pin = lane / CPP;
+        // The marker ids of an instruction's PPG positions are uniform: v_readlane + select instead of a cross-lane LDS read
+        // per instruction (a dependent ~100-cycle round trip in front of every load: the issue of a round's ~20 loads took
+        // 3.5 us, and the loads then landed too late for the next round's top)
 #pragma unroll
         for (int i = 0; i < GPT; i++) {
             const int pi = i * PPG + pin;             // position within the tile
-            const int id = __builtin_amdgcn_ds_bpermute(pi << 2, idl);
+            unsigned long long colb = 0ull;
+#pragma unroll
+            for (int h = 0; h < PPG; h++) {
+                const int sid = __builtin_amdgcn_readlane(idl, i * PPG + h);
+                const unsigned long long cb = (unsigned long long)(uintptr_t)a.bed + (unsigned long long)(unsigned)sid * (unsigned long long)a.stride;
+                colb = (PPG == 1 || pin == h) ? cb : colb;
+            }
             const int chunk = cs ^ ((16 * T + pi) & (CPP - 1));
-            const uint8_t* src = a.bed + (size_t)id * a.stride + chunk_off(chunk);
+            const uint8_t* src = reinterpret_cast<const uint8_t*>((uintptr_t)colb) + chunk_off(chunk);
             glds16(src, dst0 + (uint32_t)i * 1024u);
         }
     };
@@ -1883,6 +1924,20 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 }
             }
         }
+        if constexpr (LONGB) {
+            // packed rows: row p = both exact parts of position p's sum over this slice, row nb = those of the slice's sum of q
+            for (int vi = tid; vi <= nb; vi += SW_TPB) {
+                long long p1, p2;
+                if (vi == nb) {
+                    p1 = (long long)((s_wsq[0] + s_wsq[2] + s_wsq[4] + s_wsq[6]) * 0x1p22);      // exact: multiples of the grids
+                    p2 = (long long)((s_wsq[1] + s_wsq[3] + s_wsq[5] + s_wsq[7]) * GRID_INV);
+                } else { p1 = s_sum[2 * vi]; p2 = s_sum[2 * vi + 1]; }
+                put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)vi * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu, p1, p2);
+            }
+            b.nv = nb + 1;
+            PA(4);
+            return;
+        }
         for (int vi = tid; vi < nv0; vi += SW_TPB) {          // up to SW_VMAX values, 256 threads
             double tot;
             if (vi >= 2 * nb && vi < 2 * nb + 2) {  // sum q1, sum q2 over the slice
@@ -1917,6 +1972,50 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const unsigned long long* Pb = Pg + 2 * (size_t)(b.gen & 1u) * SW_VMAX * a.Wpad;
             unsigned long long* Tb = Ttg + 2 * (size_t)(b.gen & 1u) * SW_VMAX;
             const int rows = (b.nv - wg + W - 1) / W;         // rows wg, wg + W, ... of this workgroup (uniform)
+            if constexpr (LONGB) {
+                // packed rows (put_packed): both exact parts of a marker arrive in one granule pair; the reducer sums each part
+                // (exact: any order) and publishes ONE total, the parts added with one rounding -- what the walk did with them
+                const unsigned tag24 = (b.gen + 1u) & 0xFFFFFFu;
+                if (rows == 1) {
+                    double x1 = 0.0, x2 = 0.0;
+                    if (tid < W) {
+                        Spin sp;
+                        sp.start(spin_limit);
+                        const unsigned long long* gp = Pb + 2 * ((size_t)wg * a.Wpad + tid);
+                        while (!get_packed(gp, tag24, x1, x2)) {
+                            if (sp.expired(abort_word)) { bad = true; x1 = 0.0; x2 = 0.0; break; }
+                        }
+                    }
+                    const double r2 = reduce2(x1, x2);        // lanes 0-31: sum of x1 over the wavefront, lanes 32-63: of x2
+                    if (lane == 0) s_red[wave] = r2;
+                    if (lane == 32) s_red[4 + wave] = r2;
+                    lds_barrier();
+                    if (tid == 0)
+                        put_value(Tb + 2 * wg, b.gen + 1u, (s_red[0] + s_red[1] + s_red[2] + s_red[3]) * 0x1p-22 + (s_red[4] + s_red[5] + s_red[6] + s_red[7]) * GRID);
+                    lds_barrier();
+                } else {
+                    double* s_rows = reinterpret_cast<double*>(smem + L_TOT);       // free until wavefront 0 polls the totals
+                    for (int r = tid; r < 2 * rows; r += SW_TPB) s_rows[r] = 0.0;
+                    lds_barrier();
+                    const int total = rows * W;
+                    for (int g = tid; g < total; g += SW_TPB) {
+                        const int r = g / W, i = g - r * W;
+                        Spin sp;
+                        sp.start(spin_limit);
+                        double x1 = 0.0, x2 = 0.0;
+                        const unsigned long long* gp = Pb + 2 * ((size_t)(wg + r * W) * a.Wpad + i);
+                        while (!get_packed(gp, tag24, x1, x2)) {
+                            if (sp.expired(abort_word)) { bad = true; x1 = 0.0; x2 = 0.0; break; }
+                        }
+                        __hip_atomic_fetch_add(&s_rows[2 * r], x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&s_rows[2 * r + 1], x2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    lds_barrier();
+                    for (int r = tid; r < rows; r += SW_TPB) put_value(Tb + 2 * (wg + r * W), b.gen + 1u, s_rows[2 * r] * 0x1p-22 + s_rows[2 * r + 1] * GRID);
+                    lds_barrier();
+                }
+                return bad;
+            }
             if (rows == 1) {
                 const int v = wg;
                 double x = 0.0;
@@ -2026,7 +2125,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
             Totals tot0{0.0, 0.0, 0.0, 0.0}, tot1{0.0, 0.0, 0.0, 0.0};
             const Draws draws = sample_prepare(cur.nb, smem, (TabLds)s_tab, li_cur0.g, li_cur1.g);
-            const bool okw = poll_totals(cur.nb, cur.nv, cur.dm0, cur.dm1, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word, spin_limit);
+            const bool okw = poll_totals<LONGB>(cur.nb, cur.nv, cur.dm0, cur.dm1, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word, spin_limit);
             if (lane == 0) *reinterpret_cast<volatile int*>(&ctl[C_TOTF]) = (int)(cur.gen + 1u);   // the loaders may start
             TRACE(3);
             PROF(4);   // wait for the totals
