@@ -255,6 +255,18 @@ __device__ __forceinline__ void get_row8(const unsigned long long* base, int lan
                  : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]) : "v"(g), "v"(g2) : "memory");
 }
 
+// A register-home tile's registers, read while OTHER slots of the wavefront may have loads in flight (the staging of a stopping
+// marker's slice, after the round's tile loads have been issued).  Which slot is being loaded and which is read are different
+// by construction -- loads go to slots of tiles behind the walk, reads to tiles of the current batch (the tile window) -- but
+// no per-register data-flow can see that.  The read is therefore one asm statement that says so (an LDS store straight from
+// the accumulator registers); the checker (tools/check_prefetch_regs.py) exempts exactly these statements and keeps flagging
+// everything the COMPILER does to a register in flight (copies, spills, reads of its own).  The stores are not counted by
+// hipcc: the caller's barrier (lds_barrier: lgkmcnt(0)) is the wait.
+__device__ __forceinline__ void stage_tile_regs_guarded(uint32_t lds_dst, const u32x4& r) {
+    // (the store takes its data straight from the accumulator registers: no copy through a VGPR that the compiler would schedule)
+    asm volatile("; tile-window guarded read\n\tds_write_b128 %0, %1" : : "v"(lds_dst), "a"(r) : "memory");
+}
+
 // ---- cross-lane helpers for the wavefront reductions (gfx950: v_permlane{16,32}_swap, DPP) ----
 __device__ __forceinline__ unsigned lo32(double x) { return (unsigned)(unsigned long long)__double_as_longlong(x); }
 __device__ __forceinline__ unsigned hi32(double x) { return (unsigned)((unsigned long long)__double_as_longlong(x) >> 32); }
@@ -885,6 +897,212 @@ __device__ __noinline__ void sample_batch(int nb, int mpos0, int bmax_, int nbf1
     sample_batch_body<K, CK, LONGB>(nb, mpos0, bmax_, nbf16, G, smem, tab, lin0, lin1, tq0, tq1, Draws{p0, p1}, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
 }
 
+// ---- the walk of a long batch on four wavefronts ("parallel passes", round 4) -------------------------------
+// In the two-value layout with nothing to cross (the stationary sweeps of a block without missing genotypes) a batch holds up to
+// 240 markers and the walk is the largest item of a round: four passes of 64 markers, one after the other, on one wavefront
+// (4.4 us of a 14 us round), while wavefronts 1-3 wait.  Pass k does not depend on pass k - 1 unless that one holds the stop --
+// and then pass k is not needed at all.  So wavefront w evaluates positions 64 w .. 64 w + 63 on its own: its draws start at
+// cursor + (draws of the passes before it: one per marker whose group has sigmaG != 0, known without the totals), its
+// totals are two values of the reducers' row.  Nothing is written until every wavefront has said where its first stop is
+// (LDS, one barrier); then the wavefronts in front of the first stop commit "component 0" for their markers, the one
+// that holds it commits the markers in front of it and samples the stopping marker (bayes.cpp:450-477), the others drop
+// what they computed.  Same operations on the same values as the one-wavefront walk: the chain is the same, bit for bit.
+struct PassEval {
+    int nbp;                       // active positions of this pass (0: the batch ends before it)
+    int s;                         // first lane whose marker stops the walk (nbp: none)
+    int cursor0;                   // stream position of this pass's first draw
+    int ndraw;                     // draws of the whole pass (markers whose group has sigmaG != 0)
+    int prefix;                    // this lane's draw within the pass
+    bool sig0;                     // this lane's group has sigmaG == 0 (bayes.cpp:396-400)
+    bool active;
+};
+template <int K, class TP>
+__device__ __forceinline__ PassEval pass_eval(int nb, int base, int cursor0, const LaneIn& in, double dpa, double dpb, bool screen_on,
+                                              double inv2sige, double nm1, int G, char* smem, TP tab,
+                                              LaneTab<K>& tb, double& prob, double& acum_v, double (&muk)[K], double (&logl)[K]) {
+    const int lane = threadIdx.x & 63;
+    int* ctl = reinterpret_cast<int*>(smem + L_CTL);
+    PassEval ev;
+    ev.nbp = nb - base < 0 ? 0 : (nb - base < 64 ? nb - base : 64);
+    ev.cursor0 = cursor0;
+    ev.active = lane < ev.nbp;
+    tb = load_tab<K>(tab, G, in.g);
+    ev.sig0 = ev.active && (tb.sg == 0.0);
+    const bool use = ev.active && !ev.sig0;
+    const unsigned long long use_mask = __ballot(use);
+    ev.ndraw = __popcll(use_mask);
+    ev.prefix = __popcll(use_mask & ((1ull << lane) - 1ull));
+    const LdsStream rs{reinterpret_cast<const uint32_t*>(smem + L_RNG0), reinterpret_cast<const uint32_t*>(smem + L_RNG1), 0, nullptr};
+    prob = unif_from_word(rs.peek(cursor0 + ev.prefix));           // bayes.cpp:435
+    acum_v = 1.0;
+#pragma unroll
+    for (int i = 0; i < K; i++) { muk[i] = 0.0; logl[i] = 0.0; }
+    double num = 0.0;
+    if (use) {
+        num = in.msig * (dpa - in.mave * dpb);                       // bayes.cpp:765 (dpa, dpb: the exact sums, rounded once by the reducer)
+        num += in.beta_old * nm1;                                    // bayes.cpp:421
+    }
+    bool screened = false;                                           // (uniform) the cheap certain bound: walk_piece
+#if GM_SCREEN
+    if (screen_on) {
+        bool sure = true;
+        if (use) {
+            const double n2 = num * num;
+            float sf = 0.f;
+            bool okd = in.beta_old == 0.0;
+#pragma unroll
+            for (int i = 1; i < K; i++) {
+                const double dt = (tb.logpi[i] - tb.logpi[0]) + (tb.mhl[i] + n2 * (inv2sige * __builtin_amdgcn_rcp(tb.denom[i])));
+                okd = okd && (fabs(dt) < 690.0);                     // (false for NaN)
+                sf += __builtin_amdgcn_exp2f((float)dt * 1.44269504f);
+            }
+            sure = okd && (prob * (1.0 + 1.002 * (double)sf) <= 0.999999);
+        }
+        screened = __ballot(ev.active && !sure) == 0ull;
+        if (lane == 0 && ev.nbp > 0) { atomicAdd(&ctl[C_NSCRT], 1); if (screened) atomicAdd(&ctl[C_NSCR], 1); }
+    }
+#endif
+    if (!screened && use) acum_v = decide0<K>(num, tb, inv2sige, muk, logl);
+    const bool stop = !screened && use && (!(prob <= acum_v) || in.beta_old != 0.0);
+    const unsigned long long stop_mask = __ballot(stop);
+    ev.s = stop_mask ? (__ffsll((long long)stop_mask) - 1) : ev.nbp;
+    return ev;
+}
+// Commit one wavefront's pass.  upto: its lanes below `upto` stay in component 0 (the whole pass when the walk goes on behind it);
+// winner: lane ev.s stops the walk -- component search, draw, residual update values, the round's control words.
+template <int K>
+__device__ __forceinline__ void pass_commit(const PassEval& ev, bool winner, int nb, int base, const LaneIn& in, const LaneTab<K>& tb,
+                                            double prob, double acum_v, const double (&muk)[K], const double (&logl)[K],
+                                            double sigmae, const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16, char* smem) {
+    const int lane = threadIdx.x & 63;
+    int* ctl = reinterpret_cast<int*>(smem + L_CTL);
+    int* s_cass = reinterpret_cast<int*>(smem + l_cass);
+    const int s = ev.s;
+    const int upto = winner ? s : ev.nbp;
+    if (ev.active && lane < upto) {
+        if (ev.sig0) {
+            if (writer) out.betas_out[in.m] = 0.0;
+        } else if (writer) {                                         // component 0, effect stays 0
+            out.betas_out[in.m] = 0.0; out.comp[in.m] = 0;
+            atomicAdd(&s_cass[in.g * K + 0], 1);
+        }
+    }
+    if (!winner) return;                                             // (uniform)
+    const UpdList ul = upd_list(smem);
+    int kc = 0;
+    double acum2 = acum_v, muk_c = 0.0, denom_c = 1.0;
+    const bool need_search = __builtin_amdgcn_readlane((int)!(prob <= acum_v), s) != 0;   // wave-uniform
+    if (need_search) {
+        decide_rest_wave<K>(s, prob, acum_v, logl, kc, acum2);
+        if (lane == s) {
+#pragma unroll
+            for (int i = 1; i < K; i++)
+                if (i == kc) { muk_c = muk[i]; denom_c = tb.denom[i]; }
+        }
+    }
+    int upd = 0, cur_s = 0;
+    if (lane == s) {
+        LdsStream rs{reinterpret_cast<const uint32_t*>(smem + L_RNG0), reinterpret_cast<const uint32_t*>(smem + L_RNG1),
+                     ev.cursor0 + ev.prefix + 1, &ctl[C_RNGERR]};
+        double beta_new = 0.0;
+        if (kc > 0) beta_new = norm_lx(rs, muk_c, sigmae / denom_c, (TabLds)reinterpret_cast<const double*>(smem + L_ZNX));   // bayes.cpp:455
+        const double dbeta = in.beta_old - beta_new;                 // bayes.cpp:479
+        if (fabs(dbeta) > 0.0) {                                     // bayes.cpp:483, phenotype.cpp:328-329,388
+            upd = 1;
+            double alpha_, beta_;
+            update_values(dbeta, in.mave, in.msig, alpha_, beta_);
+            const double v1 = beta_ + alpha_;
+            ul.val[0] = beta_; ul.val[1] = v1; ul.val[2] = v1 + alpha_; ul.val[3] = 0.0;
+            ul.pos[0] = base + s;
+        }
+        if (writer) {
+            out.betas_out[in.m] = beta_new; out.comp[in.m] = kc;
+            atomicAdd(&s_cass[in.g * K + kc], 1);
+        }
+        cur_s = rs.cursor;
+        // the round's control words.  (A draw that leaves the effect as it was -- dbeta == 0 exactly -- simply ends the round
+        // behind the marker: a round boundary means nothing to the chain.)
+        const bool planned = in.beta_old != 0.0;
+        ctl[C_UPD] = upd;
+        ctl[C_SUPD] = 0;
+        ctl[C_CURSOR] = cur_s;
+        ctl[C_NDONE] = base + s + 1;
+        ctl[C_PLN] = (upd && planned) ? 1 : 0;
+        if (!(upd && planned)) {                                     // next batch size from the recent run length (walk_piece / sample_batch_body)
+            const int run = base + s + 1;
+            const int ema = (3 * ctl[C_EMA] + 16 * run) / 4;
+            ctl[C_EMA] = ema;
+            const int want = nbf16 * ema / 256;
+            int nxt = 16;
+            while (nxt < want && nxt < bmax_) nxt *= 2;
+            ctl[C_NBNEXT] = nxt > bmax_ ? bmax_ : nxt;
+        }
+    }
+}
+// ... and when no wavefront found a stop: the wavefront of the last pass closes the round
+__device__ __forceinline__ void pass_close_no_stop(const PassEval& ev, int nb, int bmax_, int nbf16, char* smem) {
+    int* ctl = reinterpret_cast<int*>(smem + L_CTL);
+    if ((threadIdx.x & 63) == 0) {
+        ctl[C_UPD] = 0; ctl[C_SUPD] = 0; ctl[C_PLN] = 0;
+        ctl[C_CURSOR] = ev.cursor0 + ev.ndraw;
+        ctl[C_NDONE] = nb;
+        const int ema = (3 * ctl[C_EMA] + 16 * 2 * nb) / 4;         // (a batch walked to its end counts as a run of twice its length)
+        ctl[C_EMA] = ema;
+        const int want = nbf16 * ema / 256;
+        int nxt = 16;
+        while (nxt < want && nxt < bmax_) nxt *= 2;
+        ctl[C_NBNEXT] = nxt > bmax_ ? bmax_ : nxt;
+    }
+}
+// One wavefront's part of a long batch's walk, start to end: evaluate my pass, meet the others, commit.  Called by all four
+// wavefronts (the barrier inside is the workgroup's).  mine: this wavefront has positions and its totals; okw: the totals arrived.
+template <int K, class TP>
+__device__ __forceinline__ void long_batch_body(int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const double* s_tot, int* s_res,
+                                                double sigmae, double inv2sige, double nm1, int G, char* smem, TP tab,
+                                                const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16) {
+    const int lane = threadIdx.x & 63;
+    const int* ctl = reinterpret_cast<const int*>(smem + L_CTL);
+    PassEval ev{0, 0, 0, 0, 0, false, false};
+    LaneTab<K> tb{};
+    double prob = 0.0, acum_v = 1.0, muk[K], logl[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) { muk[i] = 0.0; logl[i] = 0.0; }
+    if (mine) {                                                          // (uniform per wavefront)
+        const int base = 64 * wave;
+        const int pc = base + lane < nb ? base + lane : 0;
+        const double dpa = s_tot[pc], dpb = s_tot[nb];                   // one total per marker and the common one (packed exchange)
+        ev = pass_eval<K>(nb, base, cursor_w, in, dpa, dpb, ctl[C_EMA] >= ctl[C_SCRMIN], inv2sige, nm1, G, smem, tab, tb, prob, acum_v, muk, logl);
+    }
+    if (lane == 0) s_res[wave] = (mine && ev.s < ev.nbp) ? ev.s : -1;
+    lds_barrier();                                                       // every pass has reported
+    const int r0 = s_res[0], r1 = s_res[1], r2 = s_res[2], r3 = s_res[3];
+    const int wstop = r0 >= 0 ? 0 : (r1 >= 0 ? 1 : (r2 >= 0 ? 2 : (r3 >= 0 ? 3 : 4)));   // the wavefront that holds the first stop (4: none)
+    if (mine && wave <= wstop)
+        pass_commit<K>(ev, wave == wstop, nb, 64 * wave, in, tb, prob, acum_v, muk, logl, sigmae, out, writer, l_cass, bmax_, nbf16, smem);
+    if (okw && wstop == 4 && wave == ((nb - 1) >> 6)) pass_close_no_stop(ev, nb, bmax_, nbf16, smem);
+}
+template <int K, class TP>
+__device__ __noinline__ void long_batch_k(int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const double* s_tot, int* s_res,
+                                          double sigmae, double inv2sige, double nm1, int G, char* smem, TP tab,
+                                          const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16) {
+    long_batch_body<K>(nb, wave, mine, okw, cursor_w, in, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16);
+}
+// K = 4 (the reference's example mixtures) is inlined into the kernel; other K share out-of-line copies.
+template <class TP>
+__device__ __forceinline__ void long_batch_other_k(int K, int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const double* s_tot, int* s_res,
+                                                   double sigmae, double inv2sige, double nm1, int G, char* smem, TP tab,
+                                                   const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16) {
+    const LaneIn lc = in;                                                // (by address: hand over a copy, the kernel's own stays in registers)
+    switch (K) {
+        case 2: long_batch_k<2>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+        case 3: long_batch_k<3>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+        case 5: long_batch_k<5>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+        case 6: long_batch_k<6>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+        case 7: long_batch_k<7>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+        default: long_batch_k<8>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+    }
+}
+
 // rank of batch position p among the dirty markers of the batch (dm0: positions 0..63, dm1: 64..127)
 __device__ __forceinline__ int dirty_rank(unsigned long long dm0, unsigned long long dm1, int p) {
     return p < 64 ? __popcll(dm0 & ((1ull << p) - 1ull)) : __popcll(dm0) + __popcll(dm1 & ((1ull << (p - 64)) - 1ull));
@@ -1458,18 +1676,18 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     u32x4* d = reinterpret_cast<u32x4*>(stage + u * SB + 16 * kg);
                     if (k == 0) {
 #pragma unroll
-                        for (int s2 = 0; s2 < SS; s2++) { u32x4 v = rt[0][s2]; asm volatile("" : "+v"(v)); d[4 * s2] = v; }   // (opaque per slot: the three arms must not be merged into one load through a selected address -- rt would then live in scratch)
+                        for (int s2 = 0; s2 < SS; s2++) stage_tile_regs_guarded(lds_addr(d + 4 * s2), rt[0][s2]);   // (opaque per slot: the three arms must not be merged into one load through a selected address -- rt would then live in scratch)
                     }
                     if constexpr (NP > 1) {
                         if (k == 1) {
 #pragma unroll
-                            for (int s2 = 0; s2 < SS; s2++) { u32x4 v = rt[1][s2]; asm volatile("" : "+v"(v)); d[4 * s2] = v; }   // (opaque per slot: the three arms must not be merged into one load through a selected address -- rt would then live in scratch)
+                            for (int s2 = 0; s2 < SS; s2++) stage_tile_regs_guarded(lds_addr(d + 4 * s2), rt[1][s2]);   // (opaque per slot: the three arms must not be merged into one load through a selected address -- rt would then live in scratch)
                         }
                     }
                     if constexpr (NP > 2) {
                         if (k == 2) {
 #pragma unroll
-                            for (int s2 = 0; s2 < SS; s2++) { u32x4 v = rt[2][s2]; asm volatile("" : "+v"(v)); d[4 * s2] = v; }   // (opaque per slot: the three arms must not be merged into one load through a selected address -- rt would then live in scratch)
+                            for (int s2 = 0; s2 < SS; s2++) stage_tile_regs_guarded(lds_addr(d + 4 * s2), rt[2][s2]);   // (opaque per slot: the three arms must not be merged into one load through a selected address -- rt would then live in scratch)
                         }
                     }
                 }
@@ -1514,7 +1732,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         unsigned char rn0 = 1, rn1 = 1;
         if (MODE == 1) { rn0 = mr_nm[sl0]; rn1 = mr_nm[sl1]; }
         LaneIn r0i{0, 0, 0.0, 0.0, 1.0}, r1i{0, 0, 0.0, 0.0, 1.0};
-        if (wave == 0) {
+        if constexpr (LONGB) {                        // parallel passes: wavefront w samples positions 64 w .. 64 w + 63
+            const int slw = (p0 + lane + 64 * wave) & (META_POS - 1);
+            r0i = LaneIn{mr_m[slw], mr_g[slw], mr_beta[slw], mr_mave[slw], mr_msig[slw]};
+        } else if (wave == 0) {
             r0i = LaneIn{mr_m[sl0], mr_g[sl0], rb0, mr_mave[sl0], mr_msig[sl0]};
             r1i = LaneIn{mr_m[sl1], mr_g[sl1], rb1, mr_mave[sl1], mr_msig[sl1]};
         }
@@ -1609,7 +1830,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 }
             }
         }
-        {
+        if constexpr (LONGB) {
+            const bool a0 = lane + 64 * wave < nb;
+            li0 = LaneIn{a0 ? r0i.m : 0, a0 ? r0i.g : 0, a0 ? r0i.beta_old : 0.0, a0 ? r0i.mave : 0.0, a0 ? r0i.msig : 1.0};
+        } else {
             const bool a0 = wave == 0 && lane < nb, a1 = wave == 0 && lane + 64 < nb;
             li0 = LaneIn{a0 ? r0i.m : 0, a0 ? r0i.g : 0, a0 ? r0i.beta_old : 0.0, a0 ? r0i.mave : 0.0, a0 ? r0i.msig : 1.0};
             li1 = LaneIn{a1 ? r1i.m : 0, a1 ? r1i.g : 0, a1 ? r1i.beta_old : 0.0, a1 ? r1i.mave : 0.0, a1 ? r1i.msig : 1.0};
@@ -2119,7 +2343,59 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         TRACE(2);
         PROF(0);   // reduce role
 
-        // ---- sampling step of the current batch (wavefront 0, every workgroup, identical inputs)
+        }   // !fill_round
+        // The walk before this one has released tiles and sampling inputs: request what the window and the meta ring can take
+        // now (wavefronts 1-3; no gate: loads issued here, while the totals are on their way, are back before the next round's
+        // top -- behind a gate that opened when wavefront 0 had the totals they landed ~1 us late, 2.3 % of a sweep).  What
+        // is requested here is used from the NEXT round on.
+        meta_ids(fill_round ? 0 : pos + META_POS + cur.nb);
+        {
+            int t_lim = (pos >> 4) + WIN;
+            if (t_lim > ntiles) t_lim = ntiles;
+            tile_issue(t_lim, 0u, !fill_round);
+        }
+        PROF(2);   // tile / meta requests
+        if (fill_round) { lds_barrier(); continue; }  // (the loads are waited for at the top of the next round)
+
+        // ---- sampling step of the current batch (every workgroup, identical inputs)
+        if constexpr (LONGB) {
+            // parallel passes (pass_eval / pass_commit above): wavefront 0 fetches the totals row and parks it in LDS -- the other
+            // wavefronts have tile loads in flight, and a load of theirs would come back behind those --, every wavefront
+            // evaluates its 64 positions, one barrier, then the commits
+            const SampleOut so{a.acum, a.betas_out, a.comp};
+            const int nbw = cur.nb - 64 * wave;                                  // positions of this wavefront's pass (<= 0: none)
+            double* s_tot = reinterpret_cast<double*>(smem + L_TOT);
+            int* s_res = reinterpret_cast<int*>(smem + L_AB);                    // int[4]: every pass's first stop (free in this kernel)
+            // draws of the passes in front of mine: one per marker whose group has sigmaG != 0 -- known without the totals
+            int cursor_w = ctl[C_CURSOR];
+            for (int v = 0; v < wave; v++) {
+                const int gv = mr_g[(cur.p0 + 64 * v + lane) & (META_POS - 1)];
+                cursor_w += __popcll(__ballot(64 * v + lane < cur.nb && s_tab[gv] != 0.0));
+            }
+            bool okw = true;
+            if (wave == 0) {
+                const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
+                Totals t0{0.0, 0.0, 0.0, 0.0}, t1{0.0, 0.0, 0.0, 0.0};
+                okw = poll_totals<true>(cur.nb, cur.nv, 0ull, 0ull, Tb, cur.gen + 1u, smem, t0, t1, abort_word, spin_limit);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the row is in LDS before the word that says so
+                if (lane == 0) *reinterpret_cast<volatile int*>(&ctl[C_TOTF]) = okw ? (int)(cur.gen + 1u) : -1;
+                bad |= !okw;
+            } else if (nbw > 0) {
+                Spin sp;
+                sp.start(spin_limit);
+                for (;;) {
+                    const int f = *reinterpret_cast<const volatile int*>(&ctl[C_TOTF]);
+                    if (f == (int)(cur.gen + 1u)) break;
+                    if (f == -1 || sp.expired(abort_word)) { okw = false; break; }
+                }
+            }
+            TRACE(3);
+            PROF(4);   // wait for the totals
+            if (K == 4) long_batch_body<4>(cur.nb, wave, okw && nbw > 0, okw, cursor_w, li_cur0, s_tot, s_res, a.sigmae, a.inv2sige, a.nm1, G, smem, (TabLds)s_tab,
+                                           so, wg == 0, a.lds_cass, BCAP, a.nb_factor16);
+            else long_batch_other_k(K, cur.nb, wave, okw && nbw > 0, okw, cursor_w, li_cur0, s_tot, s_res, a.sigmae, a.inv2sige, a.nm1, G, smem, (TabLds)s_tab,
+                                    so, wg == 0, a.lds_cass, BCAP, a.nb_factor16);
+        } else
         if (wave == 0) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
@@ -2154,19 +2430,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 run_step((TabLds)s_tab);
             }
         }
-        PROF(7);   // sampling step (wavefront 0's own time)
-        }   // !fill_round
-        // The walk before this one has released tiles and sampling inputs: request what the window and the meta ring can take
-        // now.  Wavefronts 1-3 get here at once (they skip the block above) and issue while wavefront 0 samples; the tile loads
-        // wait for the totals (gate inside).  What is requested here is used from the NEXT round on.
-        meta_ids(fill_round ? 0 : pos + META_POS + cur.nb);
-        {
-            int t_lim = (pos >> 4) + WIN;
-            if (t_lim > ntiles) t_lim = ntiles;
-            tile_issue(t_lim, fill_round ? 0u : cur.gen + 1u, !fill_round);
-        }
-        PROF(2);   // tile / meta requests
-        if (fill_round) { lds_barrier(); continue; }  // (the loads are waited for at the top of the next round)
+        PROF(7);   // sampling step
         if (bad) ctl[C_BAD] = 1;
         lds_barrier();                                // (tile loads stay in flight)
         if (ctl[C_BAD] || ctl[C_RNGERR] || ctl[C_RANGE]) { ok = false; break; }
