@@ -260,6 +260,7 @@ static int ctx_create_body(gmrm_ctx* c, int device, int N, int M, int Mt, int S,
         HIPCHK(dalloc(&tr.comp, Mm));
         HIPCHK(dalloc(&tr.acum, Mm));
         HIPCHK(dalloc(&tr.order, Mm));
+        HIPCHK(dalloc(&tr.o_g, Mm)); HIPCHK(dalloc(&tr.o_beta, Mm)); HIPCHK(dalloc(&tr.o_mave, Mm)); HIPCHK(dalloc(&tr.o_msig, Mm)); HIPCHK(dalloc(&tr.o_nm, Mm));
         HIPCHK(dalloc(&tr.tab, (size_t)GMAX * (1 + 3 * KMAX)));
         HIPCHK(dalloc(&tr.rng_state, (size_t)624));
         HIPCHK(dalloc(&tr.rng_index, (size_t)4));
@@ -326,6 +327,7 @@ int gmrm_ctx_destroy(gmrm_ctx* c) {
         if (tr.stream) hipStreamSynchronize(tr.stream);
         hipFree(tr.eps); hipFree(tr.eps_start); hipFree(tr.namask2); hipFree(tr.mave); hipFree(tr.msig); hipFree(tr.nomiss);
         hipFree(tr.betas[0]); hipFree(tr.betas[1]); hipFree(tr.comp); hipFree(tr.acum); hipFree(tr.order);
+        hipFree(tr.o_g); hipFree(tr.o_beta); hipFree(tr.o_mave); hipFree(tr.o_msig); hipFree(tr.o_nm);
         hipFree(tr.tab); hipFree(tr.rng_state); hipFree(tr.rng_index); hipFree(tr.cass); hipFree(tr.stats);
         hipFree(tr.err); hipFree(tr.P); hipFree(tr.Tt); hipFree(tr.cnt); hipFree(tr.scratch);
         if (tr.ev0) hipEventDestroy(tr.ev0);
@@ -747,6 +749,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.bed = c->bed; a.namask2 = tr.namask2; a.order = tr.order + first; a.group = c->group;
     a.mave = tr.mave; a.msig = tr.msig; a.nomiss = tr.nomiss;
     a.betas_in = tr.betas[tr.cur]; a.betas_out = tr.betas[tr.cur ^ 1];
+    a.o_g = tr.o_g + first; a.o_beta = tr.o_beta + first; a.o_mave = tr.o_mave + first; a.o_msig = tr.o_msig + first; a.o_nm = tr.o_nm + first;
     a.comp = tr.comp; a.acum = tr.acum; a.eps = tr.eps;
     a.sigmag = tr.tab; a.denom = tr.tab + G; a.logpi = tr.tab + G + (size_t)G * K; a.mhl = tr.tab + G + 2 * (size_t)G * K;
     a.sigmae = in->sigmae;
@@ -807,7 +810,10 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
             const hipError_t se = hipStreamSynchronize(other);   // (the kernel it waits for needs nothing from this host thread)
             if (se != hipSuccess) { lk.unlock(); if (guarded) devlock_release(c->device); return hip_fail(se, "hipStreamSynchronize(other sweep)"); }
         }
-        hipError_t le = hipEventRecord(tr.ev0, st);
+        // the sampling step's inputs of this part in visit order (ops.hip, k_order_inputs: ~30 us per million markers), then the sweep
+        hipError_t le = launch_order_inputs(tr.order + first, count, c->group, tr.betas[tr.cur], tr.mave, tr.msig, tr.nomiss,
+                                            tr.o_g + first, tr.o_beta + first, tr.o_mave + first, tr.o_msig + first, tr.o_nm + first, st);
+        if (le == hipSuccess) le = hipEventRecord(tr.ev0, st);
         if (le == hipSuccess) le = launch_sweep(a, c->R, st, grid);
         if (le == hipSuccess) le = hipEventRecord(tr.ev1, st);
         if (le != hipSuccess) {

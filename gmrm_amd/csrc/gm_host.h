@@ -32,6 +32,7 @@ struct Trait {
     int G = 0, K = 0;
     // sweep workspace
     int* order = nullptr;
+    int* o_g = nullptr; double* o_beta = nullptr; double* o_mave = nullptr; double* o_msig = nullptr; uint8_t* o_nm = nullptr;   // sampling inputs in visit order
     double* tab = nullptr;
     uint32_t* rng_state = nullptr;
     int* rng_index = nullptr;

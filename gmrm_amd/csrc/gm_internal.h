@@ -27,6 +27,8 @@ struct SweepArgs {
     const double* msig;            // [M]
     const uint8_t* nomiss;         // [M] 1: the marker has no missing genotype among the phenotyped individuals
     const double* betas_in;        // [M] effects before this sweep
+    // the sampling step's inputs in visit order (k_order_inputs, run in front of the sweep): entry p = those of marker order[p]
+    const int* o_g; const double* o_beta; const double* o_mave; const double* o_msig; const uint8_t* o_nm;
     double* betas_out;             // [M] effects after this sweep
     int* comp;                     // [M]
     double* acum;                  // [M]
@@ -76,6 +78,8 @@ hipError_t launch_sumsq(const double* eps, const uint8_t* namask2 /*or null*/, s
                         double* outmax, hipStream_t st);
 hipError_t launch_marker_stats(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, int nonas,
                                double* mave, double* msig, uint8_t* nomiss, hipStream_t st);
+hipError_t launch_order_inputs(const int* order, int count, const int* group, const double* betas, const double* mave, const double* msig,
+                               const uint8_t* nomiss, int* o_g, double* o_beta, double* o_mave, double* o_msig, uint8_t* o_nm, hipStream_t st);
 hipError_t launch_recode(uint8_t* bed, size_t nbytes, int back, hipStream_t st);   // .bed code <-> device code, in place
 hipError_t launch_synth(uint8_t* bed, size_t stride, int N, int M, int S, uint64_t seed,
                         double maf, double miss, hipStream_t st);

@@ -238,6 +238,31 @@ hipError_t launch_recode(uint8_t* bed, size_t nbytes, int back, hipStream_t st) 
     return hipGetLastError();
 }
 
+// ---- the sampling step's per-marker inputs in VISIT order (round 4) --------------------------------------------
+// The sweep kernel's workgroups all need, for every order position, the marker's id, group, previous effect, mean and
+// scale.  Gathered inside the persistent kernel that was 4 loads of 64 random addresses per 64 positions and loader
+// wavefront -- the same gathers in every one of the 245 workgroups, each address another page for the address pipeline
+// the genotype loads go through.  One pass of this kernel in front of the sweep puts them in order-major arrays; the
+// sweep kernel then reads them as five contiguous streams (L2 hits: every workgroup reads the same lines).
+__global__ __launch_bounds__(256) void k_order_inputs(const int* __restrict__ order, int count, const int* __restrict__ group,
+                                                      const double* __restrict__ betas, const double* __restrict__ mave,
+                                                      const double* __restrict__ msig, const uint8_t* __restrict__ nomiss,
+                                                      int* __restrict__ o_g, double* __restrict__ o_beta, double* __restrict__ o_mave,
+                                                      double* __restrict__ o_msig, uint8_t* __restrict__ o_nm) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < count; p += gridDim.x * blockDim.x) {
+        const int m = order[p];
+        o_g[p] = group[m]; o_beta[p] = betas[m]; o_mave[p] = mave[m]; o_msig[p] = msig[m]; o_nm[p] = nomiss[m];
+    }
+}
+hipError_t launch_order_inputs(const int* order, int count, const int* group, const double* betas, const double* mave, const double* msig,
+                               const uint8_t* nomiss, int* o_g, double* o_beta, double* o_mave, double* o_msig, uint8_t* o_nm, hipStream_t st) {
+    if (count <= 0) return hipSuccess;
+    int blocks = (count + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_order_inputs, dim3(blocks), dim3(256), 0, st, order, count, group, betas, mave, msig, nomiss, o_g, o_beta, o_mave, o_msig, o_nm);
+    return hipGetLastError();
+}
+
 // ---- synthetic genotypes, keyed by (seed, global marker, byte) ------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

@@ -1444,6 +1444,14 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (lane == 32) s_wsq[wave * 2 + 1] = r2;
     };
     refresh_planes();
+#ifdef GM_SWEEP_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pa[5] = {0, 0, 0, 0, 0};      // phase A: entry barrier, scan + inputs, tiles, exit barrier, publish
+    unsigned long long tlast = __builtin_amdgcn_s_memrealtime();
+#define PA(i) do { if (tid == GM_PROF_TID) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); pa[i] += t_ - tpa; tpa = t_; } } while (0)
+#else
+#define PA(i) do { } while (0)
+#endif
 
     // ---- the tile window --------------------------------------------------------------------------------
     // Tile T = order positions 16 T .. 16 T + 15.  Its home follows from T alone (Geo<R>): register tiles T & 7 = 1, 2, 3 belong
@@ -1516,10 +1524,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     int mhi = 0, npm = 0;                             // meta ring holds positions [pos, mhi)
     int pm_m[2] = {0, 0}, pm_g[2] = {0, 0}, pm_nm[2] = {1, 1};
     double pm_beta[2] = {0.0, 0.0}, pm_mave[2] = {0.0, 0.0}, pm_msig[2] = {1.0, 1.0};
-    // in two steps: the marker ids, then -- once they are there -- what hangs on them.  Between the two the caller waits for
-    // something else (the gate of the tile loads); the second step goes in FRONT of the tile loads: a wait for ids
-    // issued behind those would be a wait for the columns (HBM latency).
-    auto meta_ids = [&](int want) __attribute__((always_inline))  {
+    // One step (round 4): the inputs sit in order-major arrays (ops.hip, k_order_inputs), so a group of 64 positions is five
+    // contiguous loads -- no ids first, no gathers of 64 random addresses (each another page for the address pipeline the
+    // genotype loads go through).  In FRONT of the tile loads (a wait for these behind those would be a wait for the columns).
+    auto meta_request = [&](int want) __attribute__((always_inline)) {
         if (want > a.M) want = a.M;
         npm = want - mhi;
         if (npm > 384) npm = 384;
@@ -1532,21 +1540,11 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     const int p = mhi + 64 * grp + lane;
                     const int pi = p < a.M ? p : a.M - 1;
                     pm_m[h] = a.order[pi];
-                }
-            }
-        }
-    };
-    auto meta_issue = [&]() __attribute__((always_inline))  {
-        if (loader) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int grp = (wave - 1) + 3 * h;
-                if (64 * grp < npm) {
-                    pm_g[h] = a.group[pm_m[h]];
-                    pm_beta[h] = a.betas_in[pm_m[h]];
-                    pm_mave[h] = a.mave[pm_m[h]];
-                    pm_msig[h] = a.msig[pm_m[h]];
-                    if (MODE == 1) pm_nm[h] = a.nomiss[pm_m[h]];
+                    pm_g[h] = a.o_g[pi];
+                    pm_beta[h] = a.o_beta[pi];
+                    pm_mave[h] = a.o_mave[pi];
+                    pm_msig[h] = a.o_msig[pi];
+                    if (MODE == 1) pm_nm[h] = a.o_nm[pi];
                 }
             }
         }
@@ -1571,7 +1569,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     };
     auto ensure_meta = [&](int upto) __attribute__((always_inline))  {                 // slow path (uniform): meta ring must hold [.., upto)
         if (mhi < upto) meta_commit();
-        while (mhi < upto) { meta_ids(upto); meta_issue(); meta_commit(); }
+        while (mhi < upto) { meta_request(upto); meta_commit(); }
     };
 
     // Request tiles [t_hi, t_lim) (at most 16 per call).  LDS tiles are shared out over the loader wavefronts by their index,
@@ -1582,55 +1580,78 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // wait until wavefront 0 has the totals (gate_tag != 0): every memory instruction of a compute unit goes through one
     // in-order address pipeline, and loads issued while wavefront 0 polls delay its looks.
     constexpr int JMAXL = RPER ? 4 : 6;               // LDS tiles one wavefront loads per call, at most
-    auto tile_issue = [&](int t_lim, unsigned gate_tag, const bool with_meta) __attribute__((always_inline)) {
-        if (t_lim > t_hi + 16) t_lim = t_hi + 16;
-        if (t_lim < t_hi) t_lim = t_hi;
+    // The marker ids of the tiles this wavefront may load next -- its register tiles (by slot) and its LDS tiles among
+    // [t_hi, t_hi + 16) -- are requested AHEAD (at the top of the round): fetched inside tile_issue they put two dependent L2
+    // round trips (ids, then the loads that hang on them) in front of the loaders' own pass of the walk, and wavefront 0 waited
+    // for them at the walk's barrier (4.6 us of "issue" per round).
+    int idq_for = -1;                                 // the ids below were requested for t_hi == idq_for (uniform)
+    int idr0 = 0, idr1 = 0, idr2 = 0;                 // lane l: the marker at row l & 15 of my register tile in slot 0 / 1 / 2
+    int idl[JMAXL];                                   // ... of my j-th LDS tile
+#pragma unroll
+    for (int j = 0; j < JMAXL; j++) idl[j] = 0;
+    // (by value, and every slot's tile by its own select: out-parameters assigned in an if / else chain became ONE store through a
+    //  selected address -- three words of scratch, and every scratch load is followed by s_waitcnt vmcnt(0): the wavefront waited
+    //  for its id loads at the top of the round and for its tile loads in the middle of issuing them)
+    struct MyTiles { int tk0, tk1, tk2; unsigned lmine; };
+    auto my_tiles = [&](int t0, int t1) __attribute__((always_inline)) -> MyTiles {   // among [t0, t1) (uniform)
+        MyTiles r{-1, -1, -1, 0u};
+        if constexpr (NP > 0) {
+            for (int T = t0 + ((wave - t0) & 7); T < t1; T += 8) {   // T & 7 == wave (1..3): a register tile of mine
+                const int k = reg_slot(T);
+                r.tk0 = (k == 0 && r.tk0 < 0) ? T : r.tk0;           // (the first per slot: with one slot a wavefront's next two tiles share it)
+                r.tk1 = (k == 1 && r.tk1 < 0) ? T : r.tk1;
+                r.tk2 = (k == 2 && r.tk2 < 0) ? T : r.tk2;
+            }
+        }
+        for (int T = t0; T < t1; T++) {
+            const bool m_ = !is_reg(T) && (1 + lds_index(T) % 3) == wave;
+            r.lmine |= (m_ ? 1u : 0u) << (T - t0);
+        }
+        return r;
+    };
+    auto id_of = [&](int T) __attribute__((always_inline)) -> int {     // lane l: the marker at position 16 T + (l & 15)
+        const int p = 16 * T + mrow;
+        return a.order[p < a.M ? p : a.M - 1];
+    };
+    auto tile_ids = [&]() __attribute__((always_inline)) {
         if (loader) {
-            t_hi = __builtin_amdgcn_readfirstlane(t_hi);
-            t_lim = __builtin_amdgcn_readfirstlane(t_lim);
-            // this wavefront's register tiles among them, by slot (uniform)
-            int tk0 = -1, tk1 = -1, tk2 = -1;
-            if constexpr (NP > 0) {
-                for (int T = t_hi + ((wave - t_hi) & 7); T < t_lim; T += 8) {   // T & 7 == wave (1..3): a register tile of mine
-                    const int k = reg_slot(T);
-                    if (k == 0) tk0 = T; else if (k == 1) tk1 = T; else tk2 = T;
-                }
-            }
-            unsigned lmine = 0u;                      // bit T - t_hi: LDS tile T is loaded by this wavefront (uniform)
-            for (int T = t_hi; T < t_lim; T++) {
-                const bool m_ = !is_reg(T) && (1 + lds_index(T) % 3) == wave;
-                lmine |= (m_ ? 1u : 0u) << (T - t_hi);
-            }
-            auto id_of = [&](int T) __attribute__((always_inline)) -> int {     // lane l: the marker at position 16 T + (l & 15)
-                const int p = 16 * T + mrow;
-                return a.order[p < a.M ? p : a.M - 1];
-            };
-            int idr0 = 0, idr1 = 0, idr2 = 0;
-            if (tk0 >= 0) idr0 = id_of(tk0);
-            if (NP > 1 && tk1 >= 0) idr1 = id_of(tk1);
-            if (NP > 2 && tk2 >= 0) idr2 = id_of(tk2);
-            int idl[JMAXL];
+            const int t0 = __builtin_amdgcn_readfirstlane(t_hi);
+            int t1 = t0 + 16;
+            if (t1 > ntiles) t1 = ntiles;
+            const MyTiles mt = my_tiles(t0, t1);
+            const int tk0 = mt.tk0, tk1 = mt.tk1, tk2 = mt.tk2;
+            const unsigned lmine = mt.lmine;
+            // (unconditional, with a harmless tile where there is none: a load merged with the old value of its register would
+            //  have to be waited for on the spot)
+            if (NP > 0) idr0 = id_of(tk0 >= 0 ? tk0 : t0);
+            if (NP > 1) idr1 = id_of(tk1 >= 0 ? tk1 : t0);
+            if (NP > 2) idr2 = id_of(tk2 >= 0 ? tk2 : t0);
             unsigned mm = lmine;
 #pragma unroll
             for (int j = 0; j < JMAXL; j++) {
-                idl[j] = 0;
-                if (mm) {                             // (uniform)
-                    const int T = __builtin_amdgcn_readfirstlane(t_hi + (__ffs((int)mm) - 1));
-                    mm &= mm - 1u;
-                    idl[j] = id_of(T);
-                }
+                const int T = __builtin_amdgcn_readfirstlane(mm ? t0 + (__ffs((int)mm) - 1) : t0);
+                mm &= mm - 1u;
+                idl[j] = id_of(T);
             }
-            if (gate_tag != 0u) {
-                Spin sp;
-                sp.start(spin_limit);
-                while (*reinterpret_cast<const volatile int*>(&ctl[C_TOTF]) != (int)gate_tag)
-                    if (sp.expired(abort_word)) break;
-            }
-            if (with_meta) meta_issue();              // (loads that depend on ids requested before the gate: they have landed by now)
+        }
+        idq_for = t_hi;
+    };
+    auto tile_issue = [&](int t_lim, int meta_want) __attribute__((always_inline)) {
+        if (t_lim > t_hi + 16) t_lim = t_hi + 16;
+        if (t_lim < t_hi) t_lim = t_hi;
+        if (idq_for != t_hi) tile_ids();              // (uniform: the ids of the tiles that may be loaded now)
+        if (meta_want > 0) meta_request(meta_want);   // (every wavefront keeps the ring's bookkeeping; the loaders load)
+        if (loader) {
+            t_hi = __builtin_amdgcn_readfirstlane(t_hi);
+            t_lim = __builtin_amdgcn_readfirstlane(t_lim);
+            const MyTiles mt = my_tiles(t_hi, t_lim); // a prefix of what tile_ids saw: the same tiles, in the same order
+            const int tk0 = mt.tk0, tk1 = mt.tk1, tk2 = mt.tk2;
+            const unsigned lmine = mt.lmine;
             if constexpr (NP > 0) { if (tk0 >= 0) load_reg_tile(std::integral_constant<int, 0>{}, idr0); }
             if constexpr (NP > 1) { if (tk1 >= 0) load_reg_tile(std::integral_constant<int, 1>{}, idr1); }
             if constexpr (NP > 2) { if (tk2 >= 0) load_reg_tile(std::integral_constant<int, 2>{}, idr2); }
-            mm = lmine;
+            PROF(3);   // (diagnostic build, loader wavefront: meta loads + register-tile loads; the LDS tiles' loads count as "requests")
+            unsigned mm = lmine;
 #pragma unroll
             for (int j = 0; j < JMAXL; j++) {
                 if (mm) {                             // (uniform)
@@ -1705,14 +1726,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     long long n_upd = 0, n_batch = 0, n_planned = 0, n_stale = 0, n_fastb = 0, n_cross = 0, n_short = 0;
     int max_nb = 0;
     bool ok = true;
-#ifdef GM_SWEEP_PROF
-    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long pa[5] = {0, 0, 0, 0, 0};      // phase A: entry barrier, scan + inputs, tiles, exit barrier, publish
-    unsigned long long tlast = __builtin_amdgcn_s_memrealtime();
-#define PA(i) do { if (tid == GM_PROF_TID) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); pa[i] += t_ - tpa; tpa = t_; } } while (0)
-#else
-#define PA(i) do { } while (0)
-#endif
 
     // phase A for positions [b.p0, b.p0 + b.nb) (their tiles are on chip) + publish
     auto compute_publish = [&](Batch& b, LaneIn& li0, LaneIn& li1) __attribute__((always_inline))  {
@@ -2348,11 +2361,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // now (wavefronts 1-3; no gate: loads issued here, while the totals are on their way, are back before the next round's
         // top -- behind a gate that opened when wavefront 0 had the totals they landed ~1 us late, 2.3 % of a sweep).  What
         // is requested here is used from the NEXT round on.
-        meta_ids(fill_round ? 0 : pos + META_POS + cur.nb);
         {
             int t_lim = (pos >> 4) + WIN;
             if (t_lim > ntiles) t_lim = ntiles;
-            tile_issue(t_lim, 0u, !fill_round);
+            tile_issue(t_lim, fill_round ? 0 : pos + META_POS + cur.nb);
         }
         PROF(2);   // tile / meta requests
         if (fill_round) { lds_barrier(); continue; }  // (the loads are waited for at the top of the next round)
