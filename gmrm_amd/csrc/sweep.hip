@@ -214,6 +214,30 @@ __device__ __forceinline__ bool get_packed(const unsigned long long* g, unsigned
     return (unsigned)(g0 >> 40) == tag24 && (unsigned)(g1 >> 40) == tag24;
 }
 
+// ... four of them per lane in one round trip (a row of up to 256 workgroups' partial sums read by ONE wavefront): pairs lane,
+// 64 + lane, 128 + lane, 192 + lane of the row at `row`; a pair that has arrived (tags match) is added to x1 / x2 once (got).
+__device__ __forceinline__ void get_packed4(const unsigned long long* row, int lane, unsigned tag24, int W, double& x1, double& x2, unsigned& got) {
+    const unsigned long long* g = row + 2 * lane;
+    u32x4 d[4];
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]) : "v"(g) : "memory");
+    const unsigned long long M40 = (1ull << 40) - 1ull;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long g0 = ((unsigned long long)d[k].y << 32) | d[k].x, g1 = ((unsigned long long)d[k].w << 32) | d[k].z;
+        const bool ok = 64 * k + lane < W && !((got >> k) & 1u) && (unsigned)(g0 >> 40) == tag24 && (unsigned)(g1 >> 40) == tag24;
+        if (ok) {
+            x1 += (double)((long long)(((g0 & M40) | ((g1 & 0xFull) << 40)) << 20) >> 20);       // exact sums of integers below 2^53
+            x2 += (double)((long long)(((g1 & M40) >> 4) << 29) >> 29);
+            got |= 1u << k;
+        }
+    }
+}
+
 // lane l of a wavefront: values l, 64+l, 128+l, 192+l of one generation's totals in a single round trip
 __device__ __forceinline__ void get_row4(const unsigned long long* base, int lane, u32x4 (&d)[4]) {
     const unsigned long long* g = base + 2 * lane;
@@ -2211,8 +2235,31 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const int rows = (b.nv - wg + W - 1) / W;         // rows wg, wg + W, ... of this workgroup (uniform)
             if constexpr (LONGB) {
                 // packed rows (put_packed): both exact parts of a marker arrive in one granule pair; the reducer sums each part
-                // (exact: any order) and publishes ONE total, the parts added with one rounding -- what the walk did with them
+                // (exact: any order) and publishes ONE total, the parts added with one rounding -- what the walk did with them.
+                // Wavefront 0 ALONE reduces (four granule pairs per lane and look): the loader wavefronts' tile loads have to
+                // flow for ~4 us per round (57 KB per workgroup, all workgroups at once), a load of theirs comes back behind
+                // whatever they requested before it, and the two exchange hops are the only stretch of the round in which
+                // nothing else needs them.  They start loading right behind the publish; wavefront 0 reduces and polls.
                 const unsigned tag24 = (b.gen + 1u) & 0xFFFFFFu;
+                if (wave != 0) return false;
+                for (int r = 0; r < rows; r++) {              // (uniform; one row unless there are fewer workgroups than rows)
+                    const int v = wg + r * W;
+                    const unsigned long long* rowp = Pb + 2 * (size_t)v * a.Wpad;
+                    double x1 = 0.0, x2 = 0.0;
+                    unsigned got = 0u;
+                    const unsigned want = (lane < W ? 1u : 0u) | (64 + lane < W ? 2u : 0u) | (128 + lane < W ? 4u : 0u) | (192 + lane < W ? 8u : 0u);
+                    Spin sp;
+                    sp.start(spin_limit);
+                    for (;;) {
+                        get_packed4(rowp, lane, tag24, W, x1, x2, got);
+                        if (__all(got == want)) break;
+                        if (sp.expired(abort_word)) { bad = true; break; }
+                    }
+                    const double r2 = reduce2(x1, x2);        // lanes 0-31: sum of x1 over the wavefront, lanes 32-63: of x2
+                    const double t1 = readlane64(r2, 0), t2 = readlane64(r2, 32);
+                    if (lane == 0) put_value(Tb + 2 * v, b.gen + 1u, t1 * 0x1p-22 + t2 * GRID);
+                }
+                return __any(bad);
                 if (rows == 1) {
                     double x1 = 0.0, x2 = 0.0;
                     if (tid < W) {
