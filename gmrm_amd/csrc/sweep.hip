@@ -2081,7 +2081,15 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     // columns 0..6: the digits of the two exact parts (the second has three: column 7 is not a plane)
                     const long long sx = planes_sum(n == 7 ? 0 : xr);
                     if (TF) {
-                        if ((n & 3) == 0 && n < 8 && in) s_sum[2 * m + (n >> 2)] = sx;
+                        if constexpr (LONGB) {
+                            // the long-batch kernel publishes from here: lane n = 0 takes the second part from lane n = 4 of its row
+                            // (DPP row_shl:4) and stores both as one packed granule pair -- no LDS round trip, no barrier, no publish
+                            // loop between a wavefront's last MFMA and its partial sums being on their way
+                            const long long s2 = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(sx >> 32), 0x104, 0xf, 0xf, false) << 32) |
+                                                             (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx, 0x104, 0xf, 0xf, false));
+                            if (n == 0 && in)
+                                put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)m * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu, sx, s2);
+                        } else if ((n & 3) == 0 && n < 8 && in) s_sum[2 * m + (n >> 2)] = sx;
                     } else {
                         // a = c - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
                         // slice's sum of d is added at the publish.  (A clean marker in this tile has Z = 0: code 3
@@ -2141,6 +2149,14 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             else if constexpr (MODE == 2) tile_pass(kr_tag, nld_tag, std::false_type{}, tR, tL0, tL1);
             else { if (dirty) tile_pass(kr_tag, nld_tag, std::false_type{}, tR, tL0, tL1); else tile_pass(kr_tag, nld_tag, std::true_type{}, tR, tL0, tL1); }
         };
+        if constexpr (LONGB) {
+            // row nb of the packed exchange: this slice's sum of q (the wavefronts' shares: refresh_planes, before the barrier above)
+            if (tid == 0) {
+                const long long p1 = (long long)((s_wsq[0] + s_wsq[2] + s_wsq[4] + s_wsq[6]) * 0x1p22);      // exact: multiples of the grids
+                const long long p2 = (long long)((s_wsq[1] + s_wsq[3] + s_wsq[5] + s_wsq[7]) * GRID_INV);
+                put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)nb * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu, p1, p2);
+            }
+        }
         {
             const int tb0 = p0 >> 4, tb1 = (p0 + nb - 1) >> 4;          // tiles of the batch
             int t = tb0 + ((wave - tb0) & 3);                           // this wavefront's first: t & 3 == wave
@@ -2166,6 +2182,12 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             }
         }
         PA(2);
+        if constexpr (LONGB) {                        // (published from the tile passes: nothing to collect)
+            b.nv = nb + 1;
+            PA(3);
+            PA(4);
+            return;
+        }
         lds_barrier();                                // the LDS sums are complete (tile loads stay in flight)
         PA(3);
         const int nv0 = 2 * nb + 2 + 2 * nd;
@@ -2184,20 +2206,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)vi * a.Wpad + wg), b.gen + 1u, (double)v);
                 }
             }
-        }
-        if constexpr (LONGB) {
-            // packed rows: row p = both exact parts of position p's sum over this slice, row nb = those of the slice's sum of q
-            for (int vi = tid; vi <= nb; vi += SW_TPB) {
-                long long p1, p2;
-                if (vi == nb) {
-                    p1 = (long long)((s_wsq[0] + s_wsq[2] + s_wsq[4] + s_wsq[6]) * 0x1p22);      // exact: multiples of the grids
-                    p2 = (long long)((s_wsq[1] + s_wsq[3] + s_wsq[5] + s_wsq[7]) * GRID_INV);
-                } else { p1 = s_sum[2 * vi]; p2 = s_sum[2 * vi + 1]; }
-                put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)vi * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu, p1, p2);
-            }
-            b.nv = nb + 1;
-            PA(4);
-            return;
         }
         for (int vi = tid; vi < nv0; vi += SW_TPB) {          // up to SW_VMAX values, 256 threads
             double tot;
