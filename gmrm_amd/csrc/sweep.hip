@@ -135,7 +135,7 @@ static int window_tiles(int rper, int nl, int np) {
     }
     return 0;
 }
-template <int R, bool CONT> static Carve carve_for(int G, int K) {
+template <int R, bool CONT, bool LONGB> static Carve carve_for(int G, int K) {
     Carve c;
     c.cass = L_VAR;
     c.tab = c.cass + (G * K * 4 + 15) / 16 * 16;
@@ -145,7 +145,7 @@ template <int R, bool CONT> static Carve carve_for(int G, int K) {
     int nl = (L_TOTAL - c.ring) / Geo<R>::TILE_B;
     if (nl > Geo<R>::NLMAX) nl = Geo<R>::NLMAX;
     c.nl = nl < 1 ? 0 : nl;
-    c.win = c.nl ? window_tiles(Geo<R>::RPER, c.nl, Geo<R>::NP) : 0;
+    c.win = c.nl ? window_tiles(LONGB ? Geo<R>::RPER : 0, c.nl, LONGB ? Geo<R>::NP : 0) : 0;
     c.nl_magic = c.nl ? (unsigned)((1ull << 32) / (unsigned)c.nl) + 1u : 0u;    // x % nl = x - nl * umulhi(x, magic) for x < 2^32 / nl (x < 2^22 here)
     return c;
 }
@@ -1361,7 +1361,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     constexpr int NI = 4 * R;                        // individuals per thread
     constexpr int ND = NI / 4;                       // dwords of a column slice a thread takes its genotypes from
     constexpr int SB = GE::SB, CPP = GE::CPP, SS = GE::SS, TILE_B = GE::TILE_B, GPT = GE::GPT, PPG = GE::PPG;
-    constexpr int RPER = GE::RPER, NP = GE::NP, NPX = NP ? NP : 1;
+    // register-home tiles only where batches are long (the two-value layout with nothing to cross): the other kernels' batches
+    // (<= 128 markers) fit the LDS tiles, and their short batches want a tile's slice split over the wavefronts (below), which a
+    // tile in ONE wavefront's registers cannot be
+    constexpr int RPER = LONGB ? GE::RPER : 0, NP = LONGB ? GE::NP : 0, NPX = NP ? NP : 1;
     constexpr int PST = GE::PSTRIDE;                 // bytes per digit plane
     constexpr int BCAP = batch_cap<MODE, CONT>();
     constexpr int NPASS = BCAP > 128 ? 4 : 2;        // groups of 64 batch positions
@@ -1393,6 +1396,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     for (int i = tid; i < 624; i += SW_TPB) s_rng0[i] = a.rng_state[i];
     for (int i = tid; i < G * K; i += SW_TPB) s_cass[i] = 0;
     for (int i = tid; i < G * (1 + 3 * K); i += SW_TPB) s_tab[i] = a.sigmag[i];
+    for (int i = tid; i < SW_VMAX; i += SW_TPB) s_sum[i] = 0;
 #ifdef GM_SWEEP_PROF
     if (tid < 8) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[tid] = 0ull;
 #endif
@@ -1484,7 +1488,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     auto is_reg = [&](int T) __attribute__((always_inline)) -> bool { return RPER != 0 && (unsigned)((T & 7) - 1) < 3u; };
     auto lds_index = [&](int T) __attribute__((always_inline)) -> int { return RPER != 0 ? 5 * (T >> 3) + ((T & 7) == 0 ? 0 : (T & 7) - 3) : T; };
     auto lds_slot = [&](int T) __attribute__((always_inline)) -> int { const int li = lds_index(T); return li - NLS * (int)__umulhi((unsigned)li, nl_magic); };
-    auto reg_slot = [&](int T) __attribute__((always_inline)) -> int { return NP > 1 ? (T >> 3) % NP : 0; };
+    auto reg_slot = [&](int T) __attribute__((always_inline)) -> int { return NP > 1 ? (T >> 3) % (NP > 1 ? NP : 1) : 0; };
     const bool loader = wave != 0;                    // wavefront 0 polls: its loads must not queue behind tile loads
     const int mrow = lane & 15, kg = lane >> 4;       // the lane's row of a 16-marker tile / its chunk within a super-step (operand A layout)
     // Byte offset of chunk c of this workgroup's slice inside a column.  Out-of-range chunks (last workgroup: its slice sticks out
@@ -1989,8 +1993,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // One pass = ONE or TWO tiles of 16 markers x SS super-steps of the slice; operand B is read once for both.  KR >= 0: the
         // first tile (tR) is register slot KR of this wavefront; NLD LDS-home tiles (tL0, tL1) follow.  All compile-time, so that the
         // body is ONE basic block; the LDS reads of super-step s + 1 are in flight during the arithmetic of s.
-        auto tile_pass = [&](auto kr_tag, auto nld_tag, auto fast_tag, int tR, int tL0, int tL1) __attribute__((always_inline))  {
+        auto tile_pass = [&](auto kr_tag, auto nld_tag, auto fast_tag, auto ns_tag, int tR, int tL0, int tL1, int ss_lo) __attribute__((always_inline))  {
             constexpr int KR = decltype(kr_tag)::value;
+            constexpr int NS = decltype(ns_tag)::value;                   // super-steps of the slice this pass covers, from ss_lo (NS < SS: the slice is split
+            constexpr bool ATOMIC = NS != SS;                             // over wavefronts, whose parts meet in LDS: integer atomics, exact in any order)
             constexpr int NLD = decltype(nld_tag)::value;
             constexpr int HR = KR >= 0 ? 1 : 0;
             constexpr int NTL = HR + NLD;                             // tiles in this pass
@@ -2014,13 +2020,14 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 acc0[q] = v4i{0, 0, 0, 0}; acc1[q] = v4i{0, 0, 0, 0}; acc2[q] = v4i{0, 0, 0, 0};
                 zcc0[q] = v4i{0, 0, 0, 0}; zcc1[q] = v4i{0, 0, 0, 0}; zcc2[q] = v4i{0, 0, 0, 0};
             }
-            auto waddr = [&](int q, int s2) __attribute__((always_inline))  { return sl0[q] + 16u * (uint32_t)((4 * s2 + kg) ^ swz[q]); };
+            auto waddr = [&](int q, int s2) __attribute__((always_inline))  { return sl0[q] + 16u * (uint32_t)((4 * (ss_lo + s2) + kg) ^ swz[q]); };
             Stage<NLD> stg[2];
-            stg[0] = stage_read<NLD>(pb0, waddr(0, 0), waddr(1, 0));
+            const uint32_t pbk = pb0 + (uint32_t)ss_lo * 256u;
+            stg[0] = stage_read<NLD>(pbk, waddr(0, 0), waddr(1, 0));
 #pragma unroll
-            for (int s2 = 0; s2 < SS; s2++) {
-                if (s2 + 1 < SS) {
-                    stg[(s2 + 1) & 1] = stage_read<NLD>(pb0 + (uint32_t)(s2 + 1) * 256u, waddr(0, s2 + 1), waddr(1, s2 + 1));
+            for (int s2 = 0; s2 < NS; s2++) {
+                if (s2 + 1 < NS) {
+                    stg[(s2 + 1) & 1] = stage_read<NLD>(pbk + (uint32_t)(s2 + 1) * 256u, waddr(0, s2 + 1), waddr(1, s2 + 1));
                     stg[s2 & 1] = stage_wait<NLD, true>(stg[s2 & 1]);
                 } else {
                     stg[s2 & 1] = stage_wait<NLD, false>(stg[s2 & 1]);
@@ -2066,6 +2073,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             // quad: planes n, n + 1 as an int32 pair (|sum| <= 2^20 per plane and slice: x + 256 x' fits), the two pairs as a 64-bit
             // integer sum_p digit_p * 256^p.  The tile has ONE owner, so the sums are stored, not added: no LDS atomics, nothing to zero.
             const int n = lane & 15;
+            auto put_sum = [&](int slot, long long v) __attribute__((always_inline)) {
+                if constexpr (ATOMIC) atomicAdd(reinterpret_cast<unsigned long long*>(&s_sum[slot]), (unsigned long long)v);
+                else s_sum[slot] = v;
+            };
             auto planes_sum = [&](int x) __attribute__((always_inline)) -> long long {                 // valid in the lanes with (n & 3) == 0
                 const int y = x + (__builtin_amdgcn_update_dpp(0, x, DPP_QUAD_1032, 0xf, 0xf, false) << 8);
                 const int y2 = __builtin_amdgcn_update_dpp(0, y, 0x4E, 0xf, 0xf, false);      // lane ^ 2
@@ -2089,7 +2100,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                                                              (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx, 0x104, 0xf, 0xf, false));
                             if (n == 0 && in)
                                 put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)m * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu, sx, s2);
-                        } else if ((n & 3) == 0 && n < 8 && in) s_sum[2 * m + (n >> 2)] = sx;
+                        } else if ((n & 3) == 0 && n < 8 && in) put_sum(2 * m + (n >> 2), sx);
                     } else {
                         // a = c - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
                         // slice's sum of d is added at the publish.  (A clean marker in this tile has Z = 0: code 3
@@ -2097,9 +2108,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                         const int zr = zcc0[q][r] + (zcc1[q][r] >> 2) + (zcc2[q][r] >> 4);
                         const long long sz = planes_sum(n == 7 ? 0 : zr);
                         if ((n & 3) == 0 && n < 8 && in) {
-                            s_sum[2 * m + (n >> 2)] = sx - 3 * sz;
+                            put_sum(2 * m + (n >> 2), sx - 3 * sz);
                             if (all_dirty || dirty_at(dm0, dm1, m))
-                                s_sum[2 * nb + 2 + 2 * (all_dirty ? m : dirty_rank(dm0, dm1, m)) + (n >> 2)] = -sz;
+                                put_sum(2 * nb + 2 + 2 * (all_dirty ? m : dirty_rank(dm0, dm1, m)) + (n >> 2), -sz);
                         }
                     }
                     // columns 8, 9: G = sum a_j a_s over the slice for the markers s the walk may cross, kept for the markers behind s
@@ -2109,7 +2120,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                             if constexpr (CK == 1) {
                                 const int x9 = __builtin_amdgcn_update_dpp(0, xr, DPP_QUAD_1032, 0xf, 0xf, false);
                                 if (n == 8 && m > ps0 && m < nb)
-                                    s_sum[2 * nb + 2 + m - ps0 - 1] = (long long)xr + ((ns > 1 && m > ps1) ? ((long long)x9 << 24) : 0ll);
+                                    put_sum(2 * nb + 2 + m - ps0 - 1, (long long)xr + ((ns > 1 && m > ps1) ? ((long long)x9 << 24) : 0ll));
                             } else if constexpr (!TF) {
                                 // all-dirty layout: column 8 = a_s, column 9 = b_s of the one stop; per marker behind it
                                 //   slot 0: G_a | G_ab << 26 = sum a_j a_s | sum a_j b_s  (a_j = c - 3 [missing]: X - 3 Z)
@@ -2120,8 +2131,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                                 const int zr9 = __builtin_amdgcn_update_dpp(0, zr, DPP_QUAD_1032, 0xf, 0xf, false);
                                 if (n == 8 && m > ps0 && m < nb) {
                                     const int sl = 4 * nb + 4 + 2 * (m - ps0 - 1);
-                                    s_sum[sl] = (long long)ga + ((long long)ga9 << 26);
-                                    s_sum[sl + 1] = (long long)zr + ((long long)zr9 << 26);
+                                    put_sum(sl, (long long)ga + ((long long)ga9 << 26));
+                                    put_sum(sl + 1, (long long)zr + ((long long)zr9 << 26));
                                 }
                             }
                         }
@@ -2144,10 +2155,18 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             for (int m = lo; m < hi; m++) d |= dirty_at(dm0, dm1, m);
             return d;
         };
+        using ICSS = std::integral_constant<int, SS>;
         auto one_pass = [&](auto kr_tag, auto nld_tag, int tR, int tL0, int tL1, bool dirty) __attribute__((always_inline))  {
-            if constexpr (MODE == 0) tile_pass(kr_tag, nld_tag, std::true_type{}, tR, tL0, tL1);
-            else if constexpr (MODE == 2) tile_pass(kr_tag, nld_tag, std::false_type{}, tR, tL0, tL1);
-            else { if (dirty) tile_pass(kr_tag, nld_tag, std::false_type{}, tR, tL0, tL1); else tile_pass(kr_tag, nld_tag, std::true_type{}, tR, tL0, tL1); }
+            if constexpr (MODE == 0) tile_pass(kr_tag, nld_tag, std::true_type{}, ICSS{}, tR, tL0, tL1, 0);
+            else if constexpr (MODE == 2) tile_pass(kr_tag, nld_tag, std::false_type{}, ICSS{}, tR, tL0, tL1, 0);
+            else { if (dirty) tile_pass(kr_tag, nld_tag, std::false_type{}, ICSS{}, tR, tL0, tL1, 0); else tile_pass(kr_tag, nld_tag, std::true_type{}, ICSS{}, tR, tL0, tL1, 0); }
+        };
+        // a batch of fewer than four tiles (every tile in LDS: the kernels without register tiles): the slice is split over the
+        // wavefronts instead -- ksplit parts per tile, met in LDS through integer atomics (s_sum is zero: the publish leaves it so)
+        auto split_pass = [&](auto ns_tag, int t, int ss_lo, bool dirty) __attribute__((always_inline))  {
+            if constexpr (MODE == 0) tile_pass(ICm1{}, IC1{}, std::true_type{}, ns_tag, 0, t, 0, ss_lo);
+            else if constexpr (MODE == 2) tile_pass(ICm1{}, IC1{}, std::false_type{}, ns_tag, 0, t, 0, ss_lo);
+            else { if (dirty) tile_pass(ICm1{}, IC1{}, std::false_type{}, ns_tag, 0, t, 0, ss_lo); else tile_pass(ICm1{}, IC1{}, std::true_type{}, ns_tag, 0, t, 0, ss_lo); }
         };
         if constexpr (LONGB) {
             // row nb of the packed exchange: this slice's sum of q (the wavefronts' shares: refresh_planes, before the barrier above)
@@ -2157,6 +2176,17 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)nb * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu, p1, p2);
             }
         }
+        const int ntb = ((p0 + nb - 1) >> 4) - (p0 >> 4) + 1;             // tiles of the batch
+        if (!LONGB && ntb < 4) {                                          // (uniform; the long-batch kernel publishes whole tiles from the pass itself)
+            const int tb0 = p0 >> 4;
+            const int tsplit = ntb >= 2 ? 2 : 1, ksplit = 4 / tsplit;     // the 4 wavefronts = tsplit tile groups x ksplit parts of the slice
+            const int wt = wave & (tsplit - 1), wk = wave / tsplit;
+#pragma unroll 1
+            for (int t = tb0 + wt; t < tb0 + ntb; t += tsplit) {
+                if (ksplit == 2) split_pass(std::integral_constant<int, SS / 2>{}, t, wk * (SS / 2), tile_dirty(t));
+                else split_pass(std::integral_constant<int, SS / 4>{}, t, wk * (SS / 4), tile_dirty(t));
+            }
+        } else
         {
             const int tb0 = p0 >> 4, tb1 = (p0 + nb - 1) >> 4;          // tiles of the batch
             int t = tb0 + ((wave - tb0) & 3);                           // this wavefront's first: t & 3 == wave
@@ -2197,6 +2227,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             if (ns > 0) {                             // (uniform) packed G counts: integers < 2^52, exact as doubles
                 for (int vi = nv0 + tid; vi < nv; vi += SW_TPB) {
                     long long v = s_sum[vi];
+                    s_sum[vi] = 0;
                     if constexpr (CK == 2) {          // the stop's own sums A_s, B_s: the wavefronts' shares of the plane build
                         if (vi < nv0 + 2) {
                             const int sh = vi == nv0 ? 0 : 16;
@@ -2227,6 +2258,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 }
                 // |sum| < 2^53 grid units: the conversion and the power-of-two scaling are exact
                 tot = (double)v * ((vi & 1) ? GRID : 0x1p-22);
+                s_sum[vi] = 0;                       // (split passes add into these slots)
             }
             put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)vi * a.Wpad + wg), b.gen + 1u, tot);
         }
@@ -2591,7 +2623,7 @@ int sweep_pick_R(size_t stride, int max_wg, int* W_out) {
 template <int R, int MODE, bool CONT> static hipError_t launch_RF(const SweepArgs& a0, hipStream_t st, int grid) {
     const int lds = L_TOTAL;
     SweepArgs a = a0;
-    const Carve cv = carve_for<R, CONT>(a.G, a.K);
+    const Carve cv = carve_for<R, CONT, (MODE == 0 && !CONT)>(a.G, a.K);
     a.lds_cass = cv.cass; a.lds_tab = cv.tab; a.lds_pln = cv.pln; a.lds_ring = cv.ring; a.nl = cv.nl; a.nl_magic = cv.nl_magic; a.win = cv.win;
     if (cv.win < 4) return hipErrorInvalidValue;     // (cannot happen for G <= 64, K <= 8: the tables leave room for several tiles)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, MODE, CONT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
