@@ -49,7 +49,7 @@ struct SweepArgs {
     int batch_init;
     unsigned long long* trace;     // diagnostic build: [W][64][8] wall-clock stamps of rounds 2000..2063, or null
     int nb_factor16;               // next batch >= nb_factor16/16 x the run-length EMA, as a power of two (default 24 = 1.5x)
-    int gate;                      // 1: the loaders' tile loads wait until wavefront 0 has the round's totals (sweep.hip, tile_issue)
+    int reduce4;                   // kernels without long batches: 1 (default) all four wavefronts take the reduce role, 0 (GMRM_REDUCE_W0=1) wavefront 0 alone
     int screen_min_run16;          // the sampling screen is tried when the run-length EMA (1/16 marker) is at least this
     int miss_mode;                 // markers with a missing genotype among the phenotyped individuals: 0 none, 1 some, 2 all
     unsigned long long spin_ticks; // every grid-wide wait gives up after this many s_memrealtime ticks (100 MHz)

@@ -2281,43 +2281,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 // whatever they requested before it, and the two exchange hops are the only stretch of the round in which
                 // nothing else needs them.  They start loading right behind the publish; wavefront 0 reduces and polls.
                 const unsigned tag24 = (b.gen + 1u) & 0xFFFFFFu;
-                if (wave != 0) return false;
-                for (int r = 0; r < rows; r++) {              // (uniform; one row unless there are fewer workgroups than rows)
-                    const int v = wg + r * W;
-                    const unsigned long long* rowp = Pb + 2 * (size_t)v * a.Wpad;
-                    double x1 = 0.0, x2 = 0.0;
-                    unsigned got = 0u;
-                    const unsigned want = (lane < W ? 1u : 0u) | (64 + lane < W ? 2u : 0u) | (128 + lane < W ? 4u : 0u) | (192 + lane < W ? 8u : 0u);
-                    Spin sp;
-                    sp.start(spin_limit);
-                    for (;;) {
-                        get_packed4(rowp, lane, tag24, W, x1, x2, got);
-                        if (__all(got == want)) break;
-                        if (sp.expired(abort_word)) { bad = true; break; }
-                    }
-                    const double r2 = reduce2(x1, x2);        // lanes 0-31: sum of x1 over the wavefront, lanes 32-63: of x2
-                    const double t1 = readlane64(r2, 0), t2 = readlane64(r2, 32);
-                    if (lane == 0) put_value(Tb + 2 * v, b.gen + 1u, t1 * 0x1p-22 + t2 * GRID);
-                }
-                return __any(bad);
-                if (rows == 1) {
-                    double x1 = 0.0, x2 = 0.0;
-                    if (tid < W) {
-                        Spin sp;
-                        sp.start(spin_limit);
-                        const unsigned long long* gp = Pb + 2 * ((size_t)wg * a.Wpad + tid);
-                        while (!get_packed(gp, tag24, x1, x2)) {
-                            if (sp.expired(abort_word)) { bad = true; x1 = 0.0; x2 = 0.0; break; }
-                        }
-                    }
-                    const double r2 = reduce2(x1, x2);        // lanes 0-31: sum of x1 over the wavefront, lanes 32-63: of x2
-                    if (lane == 0) s_red[wave] = r2;
-                    if (lane == 32) s_red[4 + wave] = r2;
-                    lds_barrier();
-                    if (tid == 0)
-                        put_value(Tb + 2 * wg, b.gen + 1u, (s_red[0] + s_red[1] + s_red[2] + s_red[3]) * 0x1p-22 + (s_red[4] + s_red[5] + s_red[6] + s_red[7]) * GRID);
-                    lds_barrier();
-                } else {
+                if (rows > 2) {
+                    // far fewer workgroups than rows (N = 50 000: 49 workgroups, up to 241 rows): row after row on one wavefront
+                    // is a memory round trip per row; all four wavefronts take granule pairs t, t + 256, ... of the rows x W this
+                    // workgroup needs and add each to its row's LDS accumulators (ds_add_f64: exact values, any order)
                     double* s_rows = reinterpret_cast<double*>(smem + L_TOT);       // free until wavefront 0 polls the totals
                     for (int r = tid; r < 2 * rows; r += SW_TPB) s_rows[r] = 0.0;
                     lds_barrier();
@@ -2337,8 +2304,59 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     lds_barrier();
                     for (int r = tid; r < rows; r += SW_TPB) put_value(Tb + 2 * (wg + r * W), b.gen + 1u, s_rows[2 * r] * 0x1p-22 + s_rows[2 * r + 1] * GRID);
                     lds_barrier();
+                    return bad;
                 }
-                return bad;
+                if (wave != 0) return false;
+                for (int r = 0; r < rows; r++) {              // (uniform; one row, two where there are fewer than 241 workgroups)
+                    const int v = wg + r * W;
+                    const unsigned long long* rowp = Pb + 2 * (size_t)v * a.Wpad;
+                    double x1 = 0.0, x2 = 0.0;
+                    unsigned got = 0u;
+                    const unsigned want = (lane < W ? 1u : 0u) | (64 + lane < W ? 2u : 0u) | (128 + lane < W ? 4u : 0u) | (192 + lane < W ? 8u : 0u);
+                    Spin sp;
+                    sp.start(spin_limit);
+                    for (;;) {
+                        get_packed4(rowp, lane, tag24, W, x1, x2, got);
+                        if (__all(got == want)) break;
+                        if (sp.expired(abort_word)) { bad = true; break; }
+                    }
+                    const double r2 = reduce2(x1, x2);        // lanes 0-31: sum of x1 over the wavefront, lanes 32-63: of x2
+                    const double t1 = readlane64(r2, 0), t2 = readlane64(r2, 32);
+                    if (lane == 0) put_value(Tb + 2 * v, b.gen + 1u, t1 * 0x1p-22 + t2 * GRID);
+                }
+                return __any(bad);
+            }
+            // The other kernels keep all four wavefronts in the reduce role (their batches are short, the loads few: measured
+            // c2 22.7 against 23.6 ms, c6 148 against 154, c5 equal); GMRM_REDUCE_W0=1 gives them the division of labour above.
+            if (!a.reduce4 && rows <= 2) {
+                if (wave != 0) return false;
+                for (int r = 0; r < rows; r++) {              // (uniform)
+                    const int v = wg + r * W;
+                    const unsigned long long* rowp = Pb + 2 * (size_t)v * a.Wpad;
+                    double x = 0.0;
+                    unsigned got = 0u;
+                    const unsigned want = (lane < W ? 1u : 0u) | (64 + lane < W ? 2u : 0u) | (128 + lane < W ? 4u : 0u) | (192 + lane < W ? 8u : 0u);
+                    Spin sp;
+                    sp.start(spin_limit);
+                    for (;;) {
+                        u32x4 d[4];
+                        get_row4(rowp, lane, d);
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (((want & ~got) >> k) & 1u) {
+                                if (d[k].y == b.gen + 1u && d[k].w == b.gen + 1u) {
+                                    x += __longlong_as_double((long long)(((unsigned long long)d[k].z << 32) | d[k].x));   // exact values: any order
+                                    got |= 1u << k;
+                                }
+                            }
+                        if (__all(got == want)) break;
+                        if (sp.expired(abort_word)) { bad = true; break; }
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+                    if (lane == 0) put_value(Tb + 2 * v, b.gen + 1u, x);
+                }
+                return __any(bad);
             }
             if (rows == 1) {
                 const int v = wg;

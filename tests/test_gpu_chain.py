@@ -305,13 +305,13 @@ def test_long_chain_stays_bit_exact(gpu):
 
 
 @pytest.mark.parametrize("env", [dict(GMRM_SWEEP_R="2"), dict(GMRM_SWEEP_R="4"),
-                                 dict(GMRM_SPEC_FACTOR16="1"), dict(GMRM_SPEC_FACTOR16="1", GMRM_NB_FACTOR16="64", GMRM_SWEEP_R="2"),
-                                 dict(GMRM_NB_FACTOR16="8")])
+                                 dict(GMRM_REDUCE_W0="1"), dict(GMRM_REDUCE_W0="1", GMRM_NB_FACTOR16="64", GMRM_SWEEP_R="2"),
+                                 dict(GMRM_NB_FACTOR16="8"), dict(GMRM_NB_FACTOR16="256", GMRM_SWEEP_R="2", GMRM_NO_CROSS="1")])
 def test_kernel_geometries_and_schedules_give_the_same_chain(gpu, monkeypatch, env):
     """The results may not depend on how the kernel is laid out or scheduled: bytes per thread
-    R = 1 / 2 / 4 (slice width, ring size, loader mapping, batch cap), speculative next batches
-    forced on (threshold 1/16 batch), larger and smaller batches.  Cases: no missing genotypes
-    (2-value exchange layout, batches up to 120) and 5 % missing (4-value layout)."""
+    R = 1 / 2 / 4 (slice width, tile window, register-home tiles at R = 2 / 4, batch cap), who takes the reduce role,
+    larger and smaller batches (up to the 240-marker cap of the long-batch kernel, kept on it by GMRM_NO_CROSS).
+    Cases: no missing genotypes (2-value exchange layout, packed partial sums) and 5 % missing (4-value layout)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for case in (cases.Case("geo_fast", 50_000, 900, 1, 4, 1, 0.0, 300, 171014, 3, 20),
