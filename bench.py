@@ -41,7 +41,13 @@ WORKLOADS = {
     # not a BASELINE configuration: c3 with missing genotypes (0.1 % of the calls) in 1 % of the markers only -- what the
     # per-batch choice of the exchange layout is for; compare its rate with c3's
     "c6": (500_000, 1_000_000, 1, 1, 0.0, 0.001),
+    # not a BASELINE configuration: c3 with linkage disequilibrium -- markers in blocks of 20 whose neighbours correlate with
+    # r ~ 0.9 (gmrm_synth_bed_ld) -- and a phenotype WITH signal (0.1 % causal markers, h2 = 0.5): correlated markers share
+    # the signal, so more of them sit in the model and more visits change an effect than with the independent draws of
+    # example/data_sim.R; the headline's sensitivity to the update rate, on record
+    "ld": (500_000, 1_000_000, 1, 1, 0.0, 0.0),
 }
+LD_BLOCKS = {"ld": (20, 0.9)}          # workload -> (block length, probability that a haplotype copies its neighbour's allele)
 DIRTY_MARKER_FRACTION = {"c6": 0.01}   # workloads whose missing genotypes sit in this fraction of the markers only
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 CPU_THREADS = 1
@@ -213,7 +219,8 @@ def main():
     t_setup = time.perf_counter()
     ctx = gmrm_amd.Context(N, M, Mt=Mt, S=S, T=T, device=local)
     dirty_frac = DIRTY_MARKER_FRACTION.get(a.workload, 0.0)
-    ctx.synth_bed(a.seed, 0.4, 0.0 if dirty_frac else miss)
+    ld_block, ld_keep = LD_BLOCKS.get(a.workload, (0, 0.0))
+    ctx.synth_bed(a.seed, 0.4, 0.0 if dirty_frac else miss, ld_block, ld_keep)
     rng = np.random.default_rng(a.seed)
     if dirty_frac:                                               # code 01 (missing) in `miss` of the calls of the first markers
         nd = max(1, int(M * dirty_frac))
@@ -226,9 +233,23 @@ def main():
         ctx.upload_bed(cols, 0)
         del cols, who, rows, byte, sh
     traits = []
+    pheno_note = "y~N(0,1)"
     for t in range(T):
         y = rng.normal(size=N)
         isna = (rng.random(N) < na_rate).astype(np.uint8) if na_rate > 0 else np.zeros(N, dtype=np.uint8)
+        if a.workload in LD_BLOCKS and world == 1:
+            # a phenotype WITH signal on the correlated markers: 0.1 % causal, h2 = 0.5, g from the device (gmrm_predict_g needs
+            # the marker statistics of SOME phenotype on these individuals: the null one first)
+            eps0, mask0, nonas0 = gmrm_amd.prepare_phenotype(y, isna)
+            ctx.upload_trait(t, eps0, mask0, nonas0)
+            ctx.compute_markers_statistics(t)
+            n_causal = max(1, Mt // 1000)
+            beta = np.zeros(ctx.M)
+            idx = rng.choice(ctx.M, size=min(n_causal, ctx.M), replace=False)
+            beta[idx] = rng.normal(0.0, np.sqrt(0.5 / n_causal), size=len(idx))
+            g = ctx.predict_g(t, beta)
+            y = g + rng.normal(0.0, np.sqrt(max(1e-6, 1.0 - float(np.var(g)))), size=N)
+            pheno_note = f"y = X beta + e, {len(idx)} causal markers (0.1 %), h2 = 0.5 (var(g) = {float(np.var(g)):.3f})"
         eps, mask4, nonas = gmrm_amd.prepare_phenotype(y, isna)
         ctx.upload_trait(t, eps, mask4, nonas)
         traits.append((eps, mask4, nonas))
@@ -291,8 +312,8 @@ def main():
         # be read inside this process); the committed summary of the same workload is quoted.
         traffic = None
         mfma_busy = None
-        pmc = ROOT / "profiles" / "r03_pmc_summary.json"
-        sq = ROOT / "profiles" / "r03_pmc_sq_summary.json"
+        pmc = ROOT / "profiles" / "r04_pmc_summary.json"
+        sq = ROOT / "profiles" / "r04_pmc_sq_summary.json"
         if a.workload == "c3" and world == 1 and not a.markers and not a.individuals:
             try:
                 traffic = json.loads(pmc.read_text())["traffic_bytes_per_launch_k_sweep"]
@@ -313,7 +334,9 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {N} individuals x {Mt} SNPs, {T} phenotype(s), {G} group(s), "
-                                   f"K=4, genotypes Binomial(2,0.4) generated on device, y~N(0,1), seed {a.seed}",
+                                   f"K=4, genotypes Binomial(2,0.4) generated on device"
+                                   + (f" in LD blocks of {ld_block} markers (neighbours r~{ld_keep})" if ld_block > 1 else "")
+                                   + f", {pheno_note}, seed {a.seed}",
                        "markers_per_gpu": M, "parallelism": f"marker-shard x{world}, 1 residual all-reduce/sweep" if a.sync_every <= 0 else
                                                             f"marker-shard x{world}, 1 residual all-reduce every {a.sync_every} markers",
                        "phenotype_na_rate": na_rate, "genotype_missing_rate": miss,
@@ -321,11 +344,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": "bytes per launch: 2 x FETCH_SIZE (the gfx950 correction for 16-B/lane loads) + WRITE_SIZE from "
-                                         "profiles/r03_pmc_summary.json (separate rocprofv3 --pmc passes of this workload, stationary sweeps)" if traffic else None,
+                                         "profiles/r04_pmc_summary.json (separate rocprofv3 --pmc passes of this workload, stationary sweeps)" if traffic else None,
                          "mfma_busy_frac": mfma_busy,
-                         "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES of the sweep kernel from profiles/r03_pmc_sq_summary.json "
+                         "mfma_busy_note": "SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES of the sweep kernel from profiles/r04_pmc_sq_summary.json "
                                            "(rocprofv3 --pmc pass of this workload): the matrix cores take the dots, but the kernel waits ~half of "
                                            "its wave-cycles (SQ_WAIT_ANY) on the grid-wide exchange" if mfma_busy is not None else None,
+                         "bytes_per_unit": mbytes,
+                         "bytes_per_unit_note": "algorithmic bytes per SNP-update = ceil(N/4): the marker's 2-bit genotype column, read once; the residual "
+                                                "and every table stay on chip for the whole sweep (DESIGN.md 5)",
                          "kernel": "gm::k_sweep (persistent marker loop)",
                          "kernel_ms_avg": avg_kernel_s * 1e3,
                          "kernel_ms_per_launch": kern_ms, "kernel_ms_warmup_launches": warm_ms,
@@ -339,6 +365,7 @@ def main():
                       "update_fraction": [u / float(M) for u in upd],
                       "planned_stops_per_sweep": planned, "stale_dots_per_sweep": stale, "crossed_stops_per_sweep": crossed,
                       "fast_layout_batches_last_sweep": smp.hyper(0).n_fast_batches,
+                      "screen_tries_last_sweep": smp.hyper(0).n_screen_tries, "screened_passes_last_sweep": smp.hyper(0).n_screened_passes,
                       "note": "a round = one batch of dots + one grid-wide exchange.  It ends at the first marker whose effect changes, "
                               "unless that marker was in the model before the visit and the walk can cross it (crossed stops: the "
                               "sums behind it are patched exactly inside the round); planned stops: rounds that ended at a marker "

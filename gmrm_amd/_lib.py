@@ -83,6 +83,7 @@ SIGNATURES = {
     "gmrm_predict_g": (C.c_int, [VP, C.c_int, c_double_p, c_double_p]),
     "gmrm_assoc": (C.c_int, [VP, C.c_int, c_double_p, c_double_p, c_double_p]),
     "gmrm_synth_bed": (C.c_int, [VP, C.c_uint64, C.c_double, C.c_double]),
+    "gmrm_synth_bed_ld": (C.c_int, [VP, C.c_uint64, C.c_double, C.c_double, C.c_int, C.c_double]),
     "gmrm_phen_prepare": (C.c_int, [c_double_p, c_u8_p, C.c_int, c_double_p, c_u8_p, c_int_p]),
     "gmrm_upload_trait": (C.c_int, [VP, C.c_int, c_double_p, c_u8_p, C.c_int]),
     "gmrm_download_eps": (C.c_int, [VP, C.c_int, c_double_p]),

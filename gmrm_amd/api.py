@@ -143,8 +143,9 @@ class Context:
         check(self.lib.gmrm_download_bed(self.h, _bp(out), int(first), int(n)))
         return out
 
-    def synth_bed(self, seed, maf=0.4, miss_rate=0.0):
-        check(self.lib.gmrm_synth_bed(self.h, int(seed), float(maf), float(miss_rate)))
+    def synth_bed(self, seed, maf=0.4, miss_rate=0.0, ld_block=0, ld_keep=0.0):
+        """Synthetic genotypes on the device; ld_block > 1: markers correlated in blocks (gmrm_synth_bed_ld)."""
+        check(self.lib.gmrm_synth_bed_ld(self.h, int(seed), float(maf), float(miss_rate), int(ld_block), float(ld_keep)))
 
     # ---- phenotypes: Phenotype ctor + read_file (src/phenotype.cpp:18-55,587-673) ----
     def upload_trait(self, t, eps, mask4, nonas):

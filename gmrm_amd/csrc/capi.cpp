@@ -374,16 +374,18 @@ int gmrm_download_bed(gmrm_ctx* c, uint8_t* cols, size_t first, size_t n) {
     return GMRM_OK;
 }
 
-int gmrm_synth_bed(gmrm_ctx* c, uint64_t seed, double maf, double miss_rate) {
+int gmrm_synth_bed_ld(gmrm_ctx* c, uint64_t seed, double maf, double miss_rate, int ld_block, double ld_keep) {
     if (!c) return fail(GMRM_EINVAL, "null context");
     if (!(maf > 0.0 && maf < 1.0) || !(miss_rate >= 0.0 && miss_rate < 1.0)) return fail(GMRM_EINVAL, "bad maf / miss_rate");
+    if (ld_block < 0 || ld_block > 4096 || !(ld_keep >= 0.0 && ld_keep < 1.0)) return fail(GMRM_EINVAL, "bad ld_block (0..4096) / ld_keep [0, 1)");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(launch_synth(c->bed, c->stride, c->N, c->M, c->S, seed, maf, miss_rate, c->tr[0].stream));
+    HIPCHK(launch_synth(c->bed, c->stride, c->N, c->M, c->S, seed, maf, miss_rate, ld_block, ld_keep, c->tr[0].stream));
     HIPCHK(hipStreamSynchronize(c->tr[0].stream));
     c->have_bed = true;
     for (auto& tr : c->tr) tr.have_stats = false;
     return GMRM_OK;
 }
+int gmrm_synth_bed(gmrm_ctx* c, uint64_t seed, double maf, double miss_rate) { return gmrm_synth_bed_ld(c, seed, maf, miss_rate, 0, 0.0); }
 
 int gmrm_phen_prepare(const double* y, const uint8_t* isna, int N, double* epsilon, uint8_t* mask4, int* nonas_out) {
     if (!y || !isna || !epsilon || !mask4 || !nonas_out || N < 2) return fail(GMRM_EINVAL, "bad argument");

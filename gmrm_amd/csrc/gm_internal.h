@@ -82,7 +82,7 @@ hipError_t launch_order_inputs(const int* order, int count, const int* group, co
                                const uint8_t* nomiss, int* o_g, double* o_beta, double* o_mave, double* o_msig, uint8_t* o_nm, hipStream_t st);
 hipError_t launch_recode(uint8_t* bed, size_t nbytes, int back, hipStream_t st);   // .bed code <-> device code, in place
 hipError_t launch_synth(uint8_t* bed, size_t stride, int N, int M, int S, uint64_t seed,
-                        double maf, double miss, hipStream_t st);
+                        double maf, double miss, int ld_block, double ld_keep, hipStream_t st);
 hipError_t launch_predict_g(const uint8_t* bed, const uint8_t* namask2, size_t stride, int M, const double* mave,
                             const double* msig, const double* beta, double* g, hipStream_t st);
 size_t predict_workspace_bytes(size_t stride, int M);

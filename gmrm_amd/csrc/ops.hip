@@ -269,25 +269,67 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
+// Correlated markers (round 4): ld_block > 1 puts the markers in blocks of ld_block consecutive (global) indices.
+// Inside a block a haplotype copies its allele from the marker before it with probability ld_keep (a 16-bit fraction) and draws
+// a fresh one otherwise (the first marker of a block always draws): neighbours correlate with r ~ ld_keep, markers k apart
+// with r ~ ld_keep^k, blocks are independent -- the shape of real linkage disequilibrium, which the reference's simulation
+// recipe (example/data_sim.R:5-41, independent Binomial(2, maf) draws) lacks.  Every allele stays a pure function of
+// (seed, marker, individual): a thread walks back to the last fresh draw (at most ld_block - 1 steps).
 __global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ bed, size_t stride, int N, int M, int S,
-                                               uint64_t seed, uint32_t maf16, uint32_t miss16) {
+                                               uint64_t seed, uint32_t maf16, uint32_t miss16, int ld_block, uint32_t ld_keep16) {
     const size_t mbytes = ((size_t)N + 3) / 4;
     const size_t total = (size_t)M * stride;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t m = i / stride, b = i % stride;
         uint8_t out = 0;
         if (b < mbytes) {
-            const uint64_t key = ((uint64_t)(S + m) * (uint64_t)mbytes + b) * 3ull;
-            const uint64_t za = mix64(seed + (key + 0) * 0x9E3779B97F4A7C15ull);
-            const uint64_t zb = mix64(seed + (key + 1) * 0x9E3779B97F4A7C15ull);
-            const uint64_t zm = mix64(seed + (key + 2) * 0x9E3779B97F4A7C15ull);
+            auto draws = [&](size_t mg, uint64_t& za, uint64_t& zb, uint64_t& zm) {
+                const uint64_t key = ((uint64_t)mg * (uint64_t)mbytes + b) * 3ull;
+                za = mix64(seed + (key + 0) * 0x9E3779B97F4A7C15ull);
+                zb = mix64(seed + (key + 1) * 0x9E3779B97F4A7C15ull);
+                zm = mix64(seed + (key + 2) * 0x9E3779B97F4A7C15ull);
+            };
+            const size_t mg = (size_t)S + m;
+            uint64_t za, zb, zm;
+            draws(mg, za, zb, zm);
+            uint32_t al_a[4], al_b[4];                      // the two haplotypes' alleles of the byte's four individuals
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                al_a[k] = ((uint32_t)(za >> (16 * k)) & 0xFFFFu) < maf16;
+                al_b[k] = ((uint32_t)(zb >> (16 * k)) & 0xFFFFu) < maf16;
+            }
+            if (ld_block > 1) {
+                // walk back through the block: haplotype h of individual k keeps copying while its "keep" draw says so
+                const int off = (int)(mg % (size_t)ld_block);
+                uint32_t open_a = 0xFu, open_b = 0xFu;       // bit k: the allele is still to be found further back
+                uint64_t ka = za, kb = zb;                   // the keep draws come from the high parts of a second mix of the same keys
+                size_t mcur = mg;
+                for (int back = 0; back < off && (open_a | open_b); back++) {
+                    const uint64_t ca = mix64(ka ^ 0xD1B54A32D192ED03ull), cb = mix64(kb ^ 0xD1B54A32D192ED03ull);
+                    uint32_t keep_a = 0, keep_b = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        keep_a |= ((((uint32_t)(ca >> (16 * k)) & 0xFFFFu) < ld_keep16) ? 1u : 0u) << k;
+                        keep_b |= ((((uint32_t)(cb >> (16 * k)) & 0xFFFFu) < ld_keep16) ? 1u : 0u) << k;
+                    }
+                    open_a &= keep_a; open_b &= keep_b;      // a haplotype that does not copy here has its allele (found at mcur)
+                    if (!(open_a | open_b)) break;
+                    mcur--;
+                    uint64_t pa, pb, pm;
+                    draws(mcur, pa, pb, pm);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if ((open_a >> k) & 1u) al_a[k] = ((uint32_t)(pa >> (16 * k)) & 0xFFFFu) < maf16;
+                        if ((open_b >> k) & 1u) al_b[k] = ((uint32_t)(pb >> (16 * k)) & 0xFFFFu) < maf16;
+                    }
+                    ka = pa; kb = pb;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (b * 4 + k >= (size_t)N) break;          // pad bits stay 00 as PLINK writes them
-                const uint32_t ua = (uint32_t)(za >> (16 * k)) & 0xFFFFu;
-                const uint32_t ub = (uint32_t)(zb >> (16 * k)) & 0xFFFFu;
                 const uint32_t um = (uint32_t)(zm >> (16 * k)) & 0xFFFFu;
-                const int copies = (ua < maf16) + (ub < maf16);
+                const int copies = (int)al_a[k] + (int)al_b[k];
                 uint32_t code = copies == 2 ? 0u : (copies == 1 ? 2u : 3u);
                 if (um < miss16) code = 1u;
                 out |= (uint8_t)(code << (2 * k));
@@ -298,11 +340,12 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ bed, size_t
 }
 
 hipError_t launch_synth(uint8_t* bed, size_t stride, int N, int M, int S, uint64_t seed, double maf, double miss,
-                        hipStream_t st) {
+                        int ld_block, double ld_keep, hipStream_t st) {
     if (M <= 0) return hipSuccess;
     const uint32_t maf16 = (uint32_t)(maf * 65536.0);
     const uint32_t miss16 = (uint32_t)(miss * 65536.0);
-    hipLaunchKernelGGL(k_synth, dim3(256 * 32), dim3(256), 0, st, bed, stride, N, M, S, seed, maf16, miss16);
+    const uint32_t keep16 = (uint32_t)(ld_keep * 65536.0);
+    hipLaunchKernelGGL(k_synth, dim3(256 * 32), dim3(256), 0, st, bed, stride, N, M, S, seed, maf16, miss16, ld_block, keep16);
     return hipGetLastError();
 }
 

@@ -97,6 +97,10 @@ int gmrm_download_bed(gmrm_ctx* ctx, uint8_t* cols, size_t first_marker, size_t 
 /* Synthetic genotypes generated on the device, keyed by (seed, global marker, individual):
  * copies of A1 ~ Binomial(2, maf) (example/data_sim.R:15), code 01 with prob. miss_rate. */
 int gmrm_synth_bed(gmrm_ctx* ctx, uint64_t seed, double maf, double miss_rate);
+/* ... with linkage disequilibrium (no upstream counterpart; example/data_sim.R draws every marker independently): markers in
+ * blocks of ld_block consecutive global indices, inside a block a haplotype copies its allele from the marker before it with
+ * probability ld_keep (r ~ ld_keep between neighbours, ld_keep^k at distance k), blocks independent.  ld_block <= 1: as above. */
+int gmrm_synth_bed_ld(gmrm_ctx* ctx, uint64_t seed, double maf, double miss_rate, int ld_block, double ld_keep);
 
 /* Phenotype::read_file after tokenising (src/phenotype.cpp:587-673), host-only: y[N] values,
  * isna[N] flags ("NA" tokens) -> eps[4*ceil(N/4)] centred and scaled to unit variance (0 at

@@ -126,6 +126,36 @@ def test_synthetic_genotypes_and_bed_roundtrip(gpu):
     ctx.close()
 
 
+def test_synthetic_genotypes_with_linkage_disequilibrium(gpu):
+    """gmrm_synth_bed_ld: markers in blocks of 8, neighbours copy a haplotype's allele with probability 0.9.  Allele frequency
+    stays at maf, neighbours inside a block correlate with r ~ 0.9 and markers two apart with r ~ 0.81, markers of different
+    blocks do not correlate; the block structure follows the GLOBAL marker index (a shard sees the same genotypes), and
+    ld_block = 0 is the independent generator bit for bit."""
+    N, M, S = 20_000, 64, 40
+    ctx = gmrm_amd.Context(N, M, Mt=1000, S=S)
+    ctx.synth_bed(7, 0.4, 0.0, ld_block=8, ld_keep=0.9)
+    bed = ctx.download_bed()
+    codes = np.stack([(bed >> (2 * k)) & 3 for k in range(4)], axis=-1).reshape(M, -1)[:, :N]
+    a = np.where(codes == 0, 2.0, np.where(codes == 2, 1.0, 0.0))
+    assert np.all(np.abs(a.mean(axis=1) - 0.8) < 0.03)
+    r = np.corrcoef(a)
+    g = S + np.arange(M)                                     # global marker indices
+    same1 = [(i, i + 1) for i in range(M - 1) if g[i] // 8 == g[i + 1] // 8]
+    same2 = [(i, i + 2) for i in range(M - 2) if g[i] // 8 == g[i + 2] // 8]
+    cross = [(i, i + 1) for i in range(M - 1) if g[i] // 8 != g[i + 1] // 8]
+    assert abs(np.mean([r[i, j] for i, j in same1]) - 0.9) < 0.02
+    assert abs(np.mean([r[i, j] for i, j in same2]) - 0.81) < 0.03
+    assert max(abs(r[i, j]) for i, j in cross) < 0.05
+    ctx2 = gmrm_amd.Context(N, 16, Mt=1000, S=S + 8)         # a shard that starts inside the block: the same genotypes
+    ctx2.synth_bed(7, 0.4, 0.0, ld_block=8, ld_keep=0.9)
+    assert np.array_equal(ctx2.download_bed(), bed[8:24])
+    ctx2.synth_bed(7, 0.4, 0.0)
+    ctx.synth_bed(7, 0.4, 0.0, ld_block=0, ld_keep=0.0)
+    assert np.array_equal(ctx2.download_bed(), ctx.download_bed(8, 16))
+    assert np.array_equal(ctx.download_bed(), _synth_numpy(N, M, S, 7, 0.4, 0.0))
+    ctx.close(); ctx2.close()
+
+
 def test_residual_exchange_is_exact(gpu):
     """delta export -> (sum over 'ranks') -> import reproduces the oracle's split2 sums."""
     import torch
