@@ -8,13 +8,15 @@ reconciled ONCE per sweep (DESIGN.md "Multi-GPU"):
 
   1. every rank draws mu on its own stream; rank 0's draw is adopted          (broadcast, T doubles)
   2. every rank launches its marker loop (persistent HIP kernel)               (no communication)
-  3. delta = eps - eps_start is pre-rounded into two exact bins and summed     (ONE all-reduce of
-     over ranks; exact, so the result does not depend on the reduction order    2*4*ceil(N/4) f64 per
-     RCCL picks                                                                 phenotype)
-  4. cass (int) is all-reduced; beta_sqn is all-gathered and summed in rank    (src/bayes.cpp:575-588)
-     order
-  5. every rank runs the hyper-parameter draws on its own stream, then adopts  (src/bayes.cpp:626,638,649)
-     rank 0's sigmag / pi_est / sigmae
+  3. ONE all-reduce (sum, f64) of one device buffer per sweep (round 4; five collectives before):
+       [ delta of every phenotype | cass | beta_sqn slots ]
+     delta = eps - eps_start pre-rounded into two exact bins (2*4*ceil(N/4) doubles per phenotype; exact, so the result
+     does not depend on the reduction order RCCL picks), written into the buffer by the library and read back from it
+     -- it never leaves the device; cass as exact doubles (src/bayes.cpp:575-588); every rank's beta_sqn in a slot of
+     its own (zeros elsewhere), so the sum IS the all-gather and the ranks add the slots in rank order, as a sequential
+     MPI_SUM would
+  4. every rank runs the hyper-parameter draws on its own stream, then adopts  (src/bayes.cpp:626,638,649)
+     rank 0's sigmag / pi_est / sigmae: one broadcast for all phenotypes
 
 iterate(it, sync_every=k) with k > 0 cuts steps 2-3 into parts of k marker positions: every rank sweeps positions
 [p k, (p + 1) k) of its own visit order, then the replicas are reconciled (step 3), and so on to the end of the longest
@@ -64,6 +66,28 @@ class HipEngine:
     def preshuffle(self):
         self.s.preshuffle()
 
+    def alloc(self, n):
+        """The exchange buffer: device memory RCCL reduces in place (host memory under host_staging)."""
+        return torch.zeros(n, dtype=torch.float64, device="cpu" if self.host_staging else self.device)
+
+    def delta_export_into(self, t, view):
+        """The two exact parts of (residual - snapshot) of phenotype t, written by the library straight into `view`
+        (a contiguous slice of the exchange buffer)."""
+        if self.host_staging:
+            self.ctx.eps_delta_export(t, self._q.data_ptr())
+            view.copy_(self._q)
+        else:
+            self.ctx.eps_delta_export(t, view.data_ptr())        # (the library synchronises its stream before it returns)
+
+    def delta_import_from(self, t, view):
+        if self.host_staging:
+            self._q.copy_(view)
+            torch.cuda.current_stream(self.device).synchronize()
+            self.ctx.eps_delta_import(t, self._q.data_ptr())
+        else:
+            self.ctx.eps_delta_import(t, view.data_ptr())
+
+    # (kept for callers that exchange phenotype by phenotype: tests/test_gpu_chain.py)
     def delta_export(self, t):
         torch.cuda.current_stream(self.device).synchronize()
         self.ctx.eps_delta_export(t, self._q.data_ptr())
@@ -97,19 +121,70 @@ class ShardedDriver:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._mmax = None
+        e = engine
+        self.nq = 2 * e.n4                               # doubles of one phenotype's delta
+        self.n_cass = e.T * e.G * e.K
+        self.n_bsq = e.T * e.G
+        self.n_delta = e.T * self.nq
+        alloc = getattr(e, "alloc", None)
+        n = self.n_delta + self.n_cass + self.world * self.n_bsq
+        self.buf = alloc(n) if alloc else torch.zeros(n, dtype=torch.float64)
+        self.collectives = 0                             # counted, for the tests and the bench line
 
-    def _exchange(self):
+    # ---- the exchange buffer: [ deltas of every phenotype | cass | beta_sqn slot of rank 0 | ... | of rank world-1 ]
+    def _export_deltas(self):
         e = self.e
         for t in range(e.T):
-            q = e.delta_export(t)
-            dist.all_reduce(q, op=dist.ReduceOp.SUM, group=self.group)
-            e.delta_import(t, q)
+            view = self.buf[t * self.nq:(t + 1) * self.nq]
+            if hasattr(e, "delta_export_into"):
+                e.delta_export_into(t, view)
+            else:                                        # (engines of the CPU tests: tensor in, tensor out)
+                view.copy_(e.delta_export(t))
+
+    def _import_deltas(self):
+        e = self.e
+        if self.buf.is_cuda:
+            torch.cuda.current_stream(self.buf.device).synchronize()     # the collective is done before the library reads
+        for t in range(e.T):
+            view = self.buf[t * self.nq:(t + 1) * self.nq]
+            if hasattr(e, "delta_import_from"):
+                e.delta_import_from(t, view)
+            else:
+                e.delta_import(t, view)
+
+    def _reduce(self, with_deltas, cass=None, bsq=None):
+        """One all-reduce over the part of the buffer that is needed; returns (cass, beta_sqn summed in rank order) when asked."""
+        lo = 0 if with_deltas else self.n_delta
+        hi = self.n_delta if cass is None else self.buf.numel()
+        if cass is not None:
+            small = np.zeros(self.n_cass + self.world * self.n_bsq)
+            small[:self.n_cass] = np.asarray(cass, dtype=np.float64).ravel()            # exact: small integers
+            o = self.n_cass + self.rank * self.n_bsq
+            small[o:o + self.n_bsq] = np.asarray(bsq, dtype=np.float64).ravel()         # this rank's slot; zeros elsewhere
+            self.buf[self.n_delta:].copy_(torch.from_numpy(small))
+        if with_deltas:
+            self._export_deltas()
+        dist.all_reduce(self.buf[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        self.collectives += 1
+        out = None
+        if cass is not None:
+            small = self.buf[self.n_delta:].cpu().numpy()                               # (waits for the collective)
+            cass_sum = np.rint(small[:self.n_cass]).astype(np.int32).reshape(np.asarray(cass).shape)
+            slots = small[self.n_cass:].reshape(self.world, -1)
+            total = slots[0].copy()
+            for r in range(1, self.world):
+                total += slots[r]                        # rank order, as a sequential MPI_SUM would
+            out = (cass_sum, total.reshape(np.asarray(bsq).shape))
+        if with_deltas:
+            self._import_deltas()
+        return out
 
     def iterate(self, it, sync_every=0):
         e = self.e
         T, G, K = e.T, e.G, e.K
         mu = e.small(np.asarray(e.draw_mu(it), dtype=np.float64))
         dist.broadcast(mu, src=0, group=self.group)
+        self.collectives += 1
         if sync_every and sync_every > 0:
             if self._mmax is None:                      # the longest block decides how many parts a sweep has
                 m = e.small(np.asarray([e.M], dtype=np.int64))
@@ -123,28 +198,27 @@ class ShardedDriver:
                 if first == 0:
                     e.preshuffle()                      # the next iteration's shuffle, beside the first part
                 e.finish_part()
-                if self.world > 1:
-                    self._exchange()
                 first += int(sync_every)
+                if self.world > 1 and first < self._mmax:
+                    self._reduce(True)                  # the deltas of this part
             cass, bsq = e.end_sweep()
+            cass, total = self._reduce(self.world > 1, cass, bsq)        # the last part's deltas ride with the counts
         else:
             e.begin_sweep(mu.cpu().numpy())
             cass, bsq = e.end_sweep()
-            if self.world > 1:                          # one shard: nothing to reconcile (exactly the
-                self._exchange()                        # reference's single-rank chain)
-        cass_t = e.small(np.ascontiguousarray(cass, dtype=np.int32))
-        dist.all_reduce(cass_t, op=dist.ReduceOp.SUM, group=self.group)
-        bsq_t = e.small(np.ascontiguousarray(bsq, dtype=np.float64))
-        parts = [torch.empty_like(bsq_t) for _ in range(self.world)]
-        dist.all_gather(parts, bsq_t, group=self.group)
-        total = parts[0].clone()
-        for p in parts[1:]:
-            total += p                                  # rank order, as a sequential MPI_SUM would
-        e.epilogue(cass_t.cpu().numpy(), total.cpu().numpy())
+            # one shard: nothing to reconcile in the residual (exactly the reference's single-rank chain)
+            cass, total = self._reduce(self.world > 1, cass, bsq)
+        e.epilogue(cass, total)
+        # rank 0's hyper-parameters for every phenotype, one broadcast
+        per = G + G * K + 1
+        pack = np.empty(T * per)
         for t in range(T):
             sg, pi, se = e.get_hyper(t)
-            pack = e.small(np.concatenate([np.asarray(sg, dtype=np.float64), np.asarray(pi, dtype=np.float64).ravel(),
-                                           [float(se)]]))
-            dist.broadcast(pack, src=0, group=self.group)
-            p = pack.cpu().numpy()
-            e.adopt(t, p[:G], p[G:G + G * K], float(p[-1]))
+            pack[t * per:(t + 1) * per] = np.concatenate([np.asarray(sg, dtype=np.float64), np.asarray(pi, dtype=np.float64).ravel(), [float(se)]])
+        pk = e.small(pack)
+        dist.broadcast(pk, src=0, group=self.group)
+        self.collectives += 1
+        p = pk.cpu().numpy()
+        for t in range(T):
+            q = p[t * per:(t + 1) * per]
+            e.adopt(t, q[:G], q[G:G + G * K], float(q[-1]))

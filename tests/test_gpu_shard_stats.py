@@ -21,7 +21,7 @@ from tests import cases
 pytestmark = pytest.mark.gpu
 
 
-def _run(n_shards, case, inp, sweeps, burn):
+def _run(n_shards, case, inp, sweeps, burn, sync_every=0):
     lib = gmrm_amd.load_library()
     traits = cases.prepare_traits(inp)
     eps, mask4, nonas = traits[0]
@@ -39,12 +39,15 @@ def _run(n_shards, case, inp, sweeps, burn):
         sa = (C.c_void_p * n_shards)(*[s.h for s in smps])
         check(lib.gmrm_group_create(C.byref(grp), n_shards, ca, sa, inp["cva"].shape[0], inp["cva"].shape[1], 0))
     sg, se, bsum, incl = [], [], np.zeros(case.M), np.zeros(case.M)
+    nupd = 0
     for it in range(1, sweeps + 1):
         if n_shards > 1:
-            check(lib.gmrm_group_iterate(grp, it))
+            check(lib.gmrm_group_iterate_parts(grp, it, int(sync_every)) if sync_every else lib.gmrm_group_iterate(grp, it))
         else:
             smps[0].iterate(it)
         hy = smps[0].hyper(0)
+        if it > burn:
+            nupd += sum(s_.hyper(0).n_updates for s_ in smps)
         sg.append(float(np.sum(hy.sigmag))); se.append(float(hy.sigmae))
         if it > burn:
             b = np.concatenate([c.betas(0) for c in ctxs])
@@ -57,7 +60,7 @@ def _run(n_shards, case, inp, sweeps, burn):
     for c in ctxs:
         c.close()
     n = sweeps - burn
-    return np.array(sg[burn:]), np.array(se[burn:]), bsum / n, incl / n
+    return np.array(sg[burn:]), np.array(se[burn:]), bsum / n, incl / n, nupd / float(n * case.M)
 
 
 def _mc_se(x, nb=10):
@@ -86,3 +89,39 @@ def test_sharded_schedule_samples_the_same_posterior_within_mc_error(gpu):
         r = np.corrcoef(ref[2], got[2])[0, 1]
         assert r > 0.97, f"{n} shards: posterior-mean effects correlate only {r:.3f} with the 1-shard chain"
         assert np.max(np.abs(ref[3][top] - got[3][top])) < 0.15, f"{n} shards: inclusion probabilities of the top markers moved"
+
+
+def test_eight_shards_and_the_exchange_period(gpu):
+    """BASELINE's partition is 8 marker shards.  With one residual exchange per sweep every shard absorbs the phenotype on its
+    own for a whole sweep: the fraction of visits that change an effect grows with the number of shards (DESIGN.md section 6:
+    the reason the predicted 8-GPU efficiency is 0.61), and markers in different shards can hold the same signal for a sweep.
+    `--sync-every k` reconciles the replicas every k markers of a block.  This test runs 8 shards with k = a whole block (once
+    per sweep), a quarter and a sixteenth of a block against the 1-shard chain on a phenotype with signal, requires every one
+    of them to agree with the sequential chain within Monte-Carlo error, and records update fraction and agreement per k
+    (printed; `pytest -s`; profiles/r04_shard_stats.txt is this table) -- the data behind the recommended default for 8 GPUs."""
+    case = cases.Case("stat8", 4000, 2048, 1, 4, 1, 0.0, 0, 4242, 0, 25)    # 25 causal markers, h2 = 0.5; 256 markers per shard
+    inp = cases.make_inputs(case)
+    inp["cva"] = np.array([[0.0, 0.0001, 0.001, 0.01]])
+    sweeps, burn = 500, 150
+    ref = _run(1, case, inp, sweeps, burn)
+    h2_ref = ref[0] / (ref[0] + ref[1])
+    assert 0.3 < h2_ref.mean() < 0.7
+    top = np.argsort(-np.abs(ref[2]))[:25]
+    block = case.M // 8
+    rows = [("1 shard", ref[4], h2_ref.mean(), 1.0, 0.0)]
+    for label, k in (("8 shards, once per sweep", 0), ("8 shards, every 1/4 block", block // 4), ("8 shards, every 1/16 block", block // 16)):
+        got = _run(8, case, inp, sweeps, burn, sync_every=k)
+        h2 = got[0] / (got[0] + got[1])
+        for name, a, b in (("sigmaG", ref[0], got[0]), ("sigmaE", ref[1], got[1]), ("h2", h2_ref, h2)):
+            tol = 4.0 * np.hypot(_mc_se(a), _mc_se(b)) + 0.03 * abs(a.mean())
+            assert abs(a.mean() - b.mean()) < tol, f"{label}: posterior mean of {name} {b.mean():.4f} vs {a.mean():.4f} (1 shard), tol {tol:.4f}"
+        r = np.corrcoef(ref[2], got[2])[0, 1]
+        dinc = float(np.max(np.abs(ref[3][top] - got[3][top])))
+        assert r > 0.96, f"{label}: posterior-mean effects correlate only {r:.3f} with the 1-shard chain"
+        assert dinc < 0.2, f"{label}: inclusion probabilities of the top markers moved by {dinc:.2f}"
+        rows.append((label, got[4], h2.mean(), r, dinc))
+    print("\nschedule                       update fraction   mean h2   corr(effects)   max |d inclusion| (top 25)")
+    for label, uf, h2m, r, dinc in rows:
+        print(f"{label:30s} {uf:10.4f} {h2m:12.4f} {r:12.4f} {dinc:14.3f}")
+    # the update fraction falls towards the sequential chain's as the replicas are reconciled more often
+    assert rows[1][1] >= rows[3][1] * 0.98
