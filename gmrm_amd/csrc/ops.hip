@@ -275,6 +275,9 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 // with r ~ ld_keep^k, blocks are independent -- the shape of real linkage disequilibrium, which the reference's simulation
 // recipe (example/data_sim.R:5-41, independent Binomial(2, maf) draws) lacks.  Every allele stays a pure function of
 // (seed, marker, individual): a thread walks back to the last fresh draw (at most ld_block - 1 steps).
+// (LD = false is the independent generator as it always was: the walk's arrays cost registers and a loop that the 125 GB
+//  block of the benchmarks should not pay for -- 549 ms instead of 25 when both shared one kernel.)
+template <bool LD>
 __global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ bed, size_t stride, int N, int M, int S,
                                                uint64_t seed, uint32_t maf16, uint32_t miss16, int ld_block, uint32_t ld_keep16) {
     const size_t mbytes = ((size_t)N + 3) / 4;
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(256) void k_synth(uint8_t* __restrict__ bed, size_t
                 al_a[k] = ((uint32_t)(za >> (16 * k)) & 0xFFFFu) < maf16;
                 al_b[k] = ((uint32_t)(zb >> (16 * k)) & 0xFFFFu) < maf16;
             }
-            if (ld_block > 1) {
+            if constexpr (LD) {
                 // walk back through the block: haplotype h of individual k keeps copying while its "keep" draw says so
                 const int off = (int)(mg % (size_t)ld_block);
                 uint32_t open_a = 0xFu, open_b = 0xFu;       // bit k: the allele is still to be found further back
@@ -345,7 +348,8 @@ hipError_t launch_synth(uint8_t* bed, size_t stride, int N, int M, int S, uint64
     const uint32_t maf16 = (uint32_t)(maf * 65536.0);
     const uint32_t miss16 = (uint32_t)(miss * 65536.0);
     const uint32_t keep16 = (uint32_t)(ld_keep * 65536.0);
-    hipLaunchKernelGGL(k_synth, dim3(256 * 32), dim3(256), 0, st, bed, stride, N, M, S, seed, maf16, miss16, ld_block, keep16);
+    if (ld_block > 1) hipLaunchKernelGGL(k_synth<true>, dim3(256 * 32), dim3(256), 0, st, bed, stride, N, M, S, seed, maf16, miss16, ld_block, keep16);
+    else hipLaunchKernelGGL(k_synth<false>, dim3(256 * 32), dim3(256), 0, st, bed, stride, N, M, S, seed, maf16, miss16, ld_block, keep16);
     return hipGetLastError();
 }
 
