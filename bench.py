@@ -261,7 +261,8 @@ def main():
     cva = np.tile(base, (G, 1))
     group_index = (np.arange(Mt) % G).astype(np.int32)
     smp = gmrm_amd.Sampler(ctx, a.seed, cva, group_index, rank=rank, nranks=world)
-    driver = ShardedDriver(HipEngine(smp, dev)) if use_pg else None
+    # GMRM_BENCH_FORCE_EXCHANGE=1: the residual exchange also with one rank (an identity) -- its host + device cost on a one-GPU box
+    driver = ShardedDriver(HipEngine(smp, dev), force_exchange=bool(os.environ.get("GMRM_BENCH_FORCE_EXCHANGE"))) if use_pg else None
     t_setup = time.perf_counter() - t_setup
 
     def step(it):
@@ -372,6 +373,8 @@ def main():
                               "that was in the model (known in advance, the batch ends there); stale dots: computed behind a stop "
                               "and thrown away"},
             "rccl_ranks": world if use_pg else 0,
+            "collectives_per_sweep": (driver.collectives / float(a.steps + a.warmup)) if driver is not None else 0,
+            "exchange_forced_with_one_rank": bool(os.environ.get("GMRM_BENCH_FORCE_EXCHANGE")) if driver is not None else False,
             "per_gpu": {"kernel_ms_avg": per_gpu_kernel_ms,
                         "roofline_frac": [(float(gmrm_amd.block_of_markers(Mt, world, r)[1]) * mbytes / (k / 1e3) / 1e9 / HBM_PEAK_GBS) if k > 0 else 0.0
                                           for r, k in enumerate(per_gpu_kernel_ms)],

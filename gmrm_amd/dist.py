@@ -115,10 +115,12 @@ class HipEngine:
 
 
 class ShardedDriver:
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, force_exchange=False):
+        """force_exchange: run the residual exchange even with ONE rank (an identity: what a one-GPU box can measure of its cost)."""
         self.e = engine
         self.group = group
         self.world = dist.get_world_size(group)
+        self.exchange = self.world > 1 or bool(force_exchange)
         self.rank = dist.get_rank(group)
         self._mmax = None
         e = engine
@@ -199,15 +201,15 @@ class ShardedDriver:
                     e.preshuffle()                      # the next iteration's shuffle, beside the first part
                 e.finish_part()
                 first += int(sync_every)
-                if self.world > 1 and first < self._mmax:
+                if self.exchange and first < self._mmax:
                     self._reduce(True)                  # the deltas of this part
             cass, bsq = e.end_sweep()
-            cass, total = self._reduce(self.world > 1, cass, bsq)        # the last part's deltas ride with the counts
+            cass, total = self._reduce(self.exchange, cass, bsq)         # the last part's deltas ride with the counts
         else:
             e.begin_sweep(mu.cpu().numpy())
             cass, bsq = e.end_sweep()
             # one shard: nothing to reconcile in the residual (exactly the reference's single-rank chain)
-            cass, total = self._reduce(self.world > 1, cass, bsq)
+            cass, total = self._reduce(self.exchange, cass, bsq)
         e.epilogue(cass, total)
         # rank 0's hyper-parameters for every phenotype, one broadcast
         per = G + G * K + 1

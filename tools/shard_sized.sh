@@ -12,6 +12,9 @@ for m in 1000000 500000 250000 125000; do
   echo "== c3 geometry, $m markers on this GPU"
   timeout -k 10 300 python3 $ROOT/bench.py --markers $m --steps 10 --warmup 5 --no-cpu-baseline --no-signal > $OUT/shard_$m.json 2> $OUT/shard_$m.err || { tail -5 $OUT/shard_$m.err; exit 1; }
 done
+echo "== the sharded driver's own cost: one rank under torchrun (RCCL), 125000 markers, residual exchange forced (an identity with one rank)"
+GMRM_BENCH_FORCE_EXCHANGE=1 timeout -k 10 300 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 \
+  $ROOT/bench.py --gpus 1 --markers 125000 --steps 20 --warmup 5 --no-cpu-baseline --no-signal > $OUT/driver_125000.json 2> $OUT/driver_125000.err || { tail -5 $OUT/driver_125000.err; exit 1; }
 for t in 1 4; do
   echo "== c2 geometry, $t phenotype(s)"
   timeout -k 10 300 python3 $ROOT/bench.py --workload c2 --traits $t --steps 10 --warmup 5 --no-cpu-baseline --no-signal > $OUT/c2_T$t.json 2> $OUT/c2_T$t.err || { tail -5 $OUT/c2_T$t.err; exit 1; }
@@ -47,6 +50,13 @@ for t in (1, 4):
     d = json.load(open(out + "/c2_T%d.json" % t))
     c2["T%d" % t] = {"value": d["value"], "ms_per_step": d["ms_per_step"], "kernel_ms_avg": d["roofline"]["kernel_ms_avg"]}
 rc = json.loads([l for l in open(out + "/rccl_one_rank.json") if l.startswith("{")][-1])   # RCCL prints a banner first
-json.dump({"shard_sized": rows, "c2_traits": c2, "rccl_one_rank": rc}, open(out + "/shard_sized.json", "w"), indent=1)
+dd = json.loads([l for l in open(out + "/driver_125000.json") if l.startswith("{")][-1])
+drv = {"what": "bench.py --gpus 1 --markers 125000 under torchrun: ShardedDriver with RCCL, one rank, residual exchange forced "
+               "(delta export -> all-reduce of the packed buffer -> import; mu and hyper broadcasts)",
+       "ms_per_step": dd["ms_per_step"], "kernel_ms_avg": dd["roofline"]["kernel_ms_avg"],
+       "host_and_exchange_ms_per_step": dd["ms_per_step"] - dd["roofline"]["kernel_ms_avg"],
+       "collectives_per_sweep": dd.get("collectives_per_sweep")}
+json.dump({"shard_sized": rows, "c2_traits": c2, "rccl_one_rank": rc, "sharded_driver_one_rank": drv}, open(out + "/shard_sized.json", "w"), indent=1)
+print(json.dumps(drv, indent=1))
 print(json.dumps({"shard_sized": [{k: (v if not isinstance(v, list) else v[-1]) for k, v in r.items()} for r in rows], "c2": c2, "rccl": rc}, indent=1))
 PY
