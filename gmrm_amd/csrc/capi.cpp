@@ -229,6 +229,9 @@ static int ctx_create_body(gmrm_ctx* c, int device, int N, int M, int Mt, int S,
     }
     env_int("GMRM_NB_FACTOR16", 8, 256, &c->nb_factor16);
     env_int("GMRM_CROSS_FRAC16", 1, 16, &c->cross_frac16);
+    env_int("GMRM_LONG_CROSS", 0, 2, &c->long_cross);
+    env_int("GMRM_BATCH_CAP", 16, 240, &c->batch_cap);
+    env_int("GMRM_LONG_CROSS_FRAC16", 1, 16, &c->long_cross_frac16);
     if (const char* e = std::getenv("GMRM_CROSS_DENSITY")) {
         const double v = std::atof(e);
         if (v >= 0.0 && v <= 1.0) c->cross_density = v;
@@ -761,6 +764,8 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.cass = tr.cass; a.stats = tr.stats; a.err = tr.err;
     a.P = tr.P; a.Tt = tr.Tt; a.cnt = tr.cnt;
     a.batch_init = c->batch_init;
+    a.bcap = c->batch_cap;
+    a.tile_trim = std::getenv("GMRM_NO_TILE_TRIM") ? 0 : 1;         // A/B knob (sweep.hip, the batch at the top of a round)
     a.trace = nullptr;
     if (std::getenv("GMRM_SWEEP_TRACE")) {                  // diagnostic build only
         if (!tr.trace) HIPCHK(hipMalloc(reinterpret_cast<void**>(&tr.trace), (size_t)256 * 64 * 8 * 8));
@@ -782,9 +787,16 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     // 500k x 1M: 7.8 % in the model 690 -> 470 ms per sweep, 1.7 % 202 -> 181, 0.36 % (stationary) 132 -> 136.  The chain
     // is the same either way, bit for bit.  GMRM_NO_CROSS=1 / GMRM_FORCE_CROSS=1: A/B knobs.
     a.cross = 0;
+    a.long_cross = 0;
     if ((a.miss_mode == 0 || a.miss_mode == 2) && !std::getenv("GMRM_NO_CROSS")) {      // (the mixed layout, mode 1, has no such kernel)
         const bool dense = (double)tr.in_model >= c->cross_density * (double)c->M;      // (as of the last completed sweep)
         if (dense || std::getenv("GMRM_FORCE_CROSS")) a.cross = c->cross_frac16;
+        // Sparse models in the layout without missing genotypes (the stationary sweeps): the long-batch kernel that crosses stops --
+        // batches of up to 240 markers, the walk on four wavefronts, the exact sums exchanged (sweep.hip, long_cont_body).  Exact
+        // and tested, but NOT the default: on 500k x 1M it takes 12 % fewer rounds and 10 % more time (a crossing costs about as
+        // much as the round it saves while the tile window holds 22 tiles: profiles/r04_ab_long_batch_crossing.txt).
+        // GMRM_LONG_CROSS=1: in sparse models; 2: in dense models as well.
+        if (a.miss_mode == 0 && c->long_cross > 0 && (!dense || c->long_cross > 1)) { a.cross = c->long_cross_frac16; a.long_cross = 1; }
     }
     a.spin_ticks = (unsigned long long)c->spin_timeout_ms * 100000ull;      // s_memrealtime ticks (100 MHz)
     // Phenotypes that do not fit side by side share stream 0 and run one after another.
@@ -901,6 +913,8 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
             std::fprintf(stderr, "[sweep prof phase A wg W/2] loop top -> barrier %.2fus scan+inputs %.2fus tiles %.2fus barrier %.2fus publish %.2fus (max batch %lld)\n",
                          st[24] * 0.01 / (double)st[1], st[25] * 0.01 / (double)st[1], st[26] * 0.01 / (double)st[1],
                          st[27] * 0.01 / (double)st[1], st[28] * 0.01 / (double)st[1], st[2]);
+            std::fprintf(stderr, "[sweep prof loop top wg W/2] meta commit %.2fus batch bookkeeping %.2fus wait for tile loads %.2fus (the rest of 'loop top -> barrier' is the barrier)\n",
+                         st[35] * 0.01 / (double)st[1], st[36] * 0.01 / (double)st[1], st[37] * 0.01 / (double)st[1]);
         }
         if (out->cass) std::memcpy(out->cass, hc.data(), sizeof(int) * (size_t)tr.G * tr.K);
         HIPCHK(hipMemcpy(out->rng_state, tr.rng_state, 624 * sizeof(uint32_t), hipMemcpyDeviceToHost));

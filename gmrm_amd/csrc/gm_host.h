@@ -67,6 +67,9 @@ struct gmrm_ctx {
     bool concurrent = true, have_bed = false, have_groups = false;
     double cross_density = 0.01;    // launch the kernel that crosses stops when at least this fraction of the block's markers is in the model (env GMRM_CROSS_DENSITY)
     int cross_frac16 = 9;           // the walk crosses a marker with a non-zero effect when at least this many sixteenths of the batch lie behind it (env GMRM_CROSS_FRAC16)
+    int long_cross = 0;                                           // the long-batch kernel that crosses stops (env GMRM_LONG_CROSS: 1 in sparse models, 2 in dense models too; measured slower: DESIGN.md 9)
+    int long_cross_frac16 = 5;                                    // ... when at least this many sixteenths of the batch lie behind the marker (env GMRM_LONG_CROSS_FRAC16)
+    int batch_cap = 0;                                            // long-batch kernels: longest batch (env GMRM_BATCH_CAP; 0: the kernel's cap, 240)
     int batch_init = 16, nb_factor16 = 24;                        // sweep schedule knobs (env GMRM_NB_FACTOR16)
     int screen_min_run16 = 16 * 48;                               // the sampling screen is tried from this recent run length on (env GMRM_SCREEN_MIN_RUN16)
 };

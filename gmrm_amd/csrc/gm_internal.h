@@ -47,6 +47,8 @@ struct SweepArgs {
     double* Tt;                    // [SW_VMAX] totals
     unsigned* cnt;                 // [96] arrival counters / abort word, zeroed per launch
     int batch_init;
+    int tile_trim;                 // 1: a batch that would give one wavefront a tile more than the others drops its last, partial tile
+    int bcap;                      // long-batch kernels: longest batch (0: the kernel's own cap; env GMRM_BATCH_CAP)
     unsigned long long* trace;     // diagnostic build: [W][64][8] wall-clock stamps of rounds 2000..2063, or null
     int nb_factor16;               // next batch >= nb_factor16/16 x the run-length EMA, as a power of two (default 24 = 1.5x)
     int reduce4;                   // kernels without long batches: 1 (default) all four wavefronts take the reduce role, 0 (GMRM_REDUCE_W0=1) wavefront 0 alone
@@ -60,6 +62,8 @@ struct SweepArgs {
     unsigned nl_magic;
     int cross;                     // > 0: the walk may cross a marker whose effect was non-zero when at least cross/16 of the batch
                                    // lies behind it (a crossing costs about half a round; 0: never)
+    int long_cross;                // with cross > 0 in the layout without missing genotypes: the long-batch kernel that crosses stops
+                                   // (sparse models) instead of the short-batch one (dense models)
 };
 
 // sweep.hip

@@ -88,7 +88,7 @@ template <int R, bool CONT> constexpr int planes_bytes() { return (7 + (CONT ? N
 // the longest batch: 240 markers where two values per marker are exchanged and nothing is crossed (four passes of the sampling
 // wavefront); 128 in the other layouts (two passes, as before: their batches end at the first marker in the model or run out
 // of exchange slots long before)
-template <int MODE, bool CONT> constexpr int batch_cap() { return (MODE == 0 && !CONT) ? 240 : 128; }
+template <bool LONG> constexpr int batch_cap() { return LONG ? 240 : 128; }
 
 // ---- LDS carve (bytes, all multiples of 16) --------------------------------------------
 constexpr int L_CTL  = 96;                      // int[16]      control words
@@ -150,8 +150,8 @@ template <int R, bool CONT, bool LONGB> static Carve carve_for(int G, int K) {
     return c;
 }
 
-enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD, C_TOTF, C_RANGE, C_PLN, C_SCRMIN, C_NSCRT, C_NSCR };
-static_assert(C_NSCR < 16, "control words");
+enum { C_NDONE = 0, C_UPD, C_SUPD, C_NBNEXT, C_CURSOR, C_EMA, C_RNGERR, C_BAD, C_TOTF, C_RANGE, C_PLN, C_SCRMIN, C_NSCRT, C_NSCR, C_XFLAG };
+static_assert(C_XFLAG < 16, "control words");
 
 size_t sweep_lds_bytes() { return (size_t)L_TOTAL; }
 
@@ -236,6 +236,27 @@ __device__ __forceinline__ void get_packed4(const unsigned long long* row, int l
             got |= 1u << k;
         }
     }
+}
+
+// Totals of the long-batch kernel that crosses stops: the walk patches the sums of the markers behind a crossed stop, and a
+// patch is exact only on the exact sum -- so the reducer publishes the sum itself instead of its rounding.  A row's sum in grid
+// units (2^-44) is S = P1 2^22 + P2 (P1: the parts on the 2^-22 grid, |P1| < 2^51; P2: the rest); it travels as h = floor(S / 2^22)
+// (53 bits, signed) and l = S mod 2^22 (the pair exact_split makes of it: the walk adds h 2^-22 and l 2^-44 with one rounding,
+// what every other kernel does with the two totals of a marker) beside two 24-bit tags:
+//   granule 0 = {h bits 0..39, tag}     granule 1 = {h bits 40..52 | l << 13, tag}
+// The rows of the crossed stops' genotype products (G of stop 0 | G of stop 1 << 24, each below 2^23) use h alone.
+__device__ __forceinline__ void put_total_x(unsigned long long* g, unsigned tag24, long long h, unsigned l) {
+    const unsigned long long M40 = (1ull << 40) - 1ull;
+    const unsigned long long g0 = ((unsigned long long)h & M40) | ((unsigned long long)tag24 << 40);
+    const unsigned long long g1 = (((unsigned long long)h >> 40) & 0x1FFFull) | ((unsigned long long)(l & 0x3FFFFFu) << 13) | ((unsigned long long)tag24 << 40);
+    const u32x4 d = {(unsigned)g0, (unsigned)(g0 >> 32), (unsigned)g1, (unsigned)(g1 >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(g), "v"(d) : "memory");
+}
+__device__ __forceinline__ void total_x_decode(const u32x4 d, long long& h, int& l) {
+    const unsigned long long g0 = ((unsigned long long)d.y << 32) | d.x, g1 = ((unsigned long long)d.w << 32) | d.z;
+    const unsigned long long M40 = (1ull << 40) - 1ull;
+    h = (long long)(((g0 & M40) | ((g1 & 0x1FFFull) << 40)) << 11) >> 11;                       // sign-extend 53 bits
+    l = (int)((g1 >> 13) & 0x3FFFFFull);
 }
 
 // lane l of a wavefront: values l, 64+l, 128+l, 192+l of one generation's totals in a single round trip
@@ -939,9 +960,11 @@ struct PassEval {
     int prefix;                    // this lane's draw within the pass
     bool sig0;                     // this lane's group has sigmaG == 0 (bayes.cpp:396-400)
     bool active;
+    unsigned long long use_mask;   // the lanes that draw
 };
+// lo: the lanes below it have been walked already (a continuation behind a crossed stop; 0 otherwise)
 template <int K, class TP>
-__device__ __forceinline__ PassEval pass_eval(int nb, int base, int cursor0, const LaneIn& in, double dpa, double dpb, bool screen_on,
+__device__ __forceinline__ PassEval pass_eval(int nb, int base, int lo, int cursor0, const LaneIn& in, double dpa, double dpb, bool screen_on,
                                               double inv2sige, double nm1, int G, char* smem, TP tab,
                                               LaneTab<K>& tb, double& prob, double& acum_v, double (&muk)[K], double (&logl)[K]) {
     const int lane = threadIdx.x & 63;
@@ -949,11 +972,12 @@ __device__ __forceinline__ PassEval pass_eval(int nb, int base, int cursor0, con
     PassEval ev;
     ev.nbp = nb - base < 0 ? 0 : (nb - base < 64 ? nb - base : 64);
     ev.cursor0 = cursor0;
-    ev.active = lane < ev.nbp;
+    ev.active = lane < ev.nbp && lane >= lo;
     tb = load_tab<K>(tab, G, in.g);
     ev.sig0 = ev.active && (tb.sg == 0.0);
     const bool use = ev.active && !ev.sig0;
     const unsigned long long use_mask = __ballot(use);
+    ev.use_mask = use_mask;
     ev.ndraw = __popcll(use_mask);
     ev.prefix = __popcll(use_mask & ((1ull << lane) - 1ull));
     const LdsStream rs{reinterpret_cast<const uint32_t*>(smem + L_RNG0), reinterpret_cast<const uint32_t*>(smem + L_RNG1), 0, nullptr};
@@ -1086,7 +1110,7 @@ __device__ __forceinline__ void long_batch_body(int nb, int wave, bool mine, boo
                                                 const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16) {
     const int lane = threadIdx.x & 63;
     const int* ctl = reinterpret_cast<const int*>(smem + L_CTL);
-    PassEval ev{0, 0, 0, 0, 0, false, false};
+    PassEval ev{0, 0, 0, 0, 0, false, false, 0ull};
     LaneTab<K> tb{};
     double prob = 0.0, acum_v = 1.0, muk[K], logl[K];
 #pragma unroll
@@ -1095,7 +1119,7 @@ __device__ __forceinline__ void long_batch_body(int nb, int wave, bool mine, boo
         const int base = 64 * wave;
         const int pc = base + lane < nb ? base + lane : 0;
         const double dpa = s_tot[pc], dpb = s_tot[nb];                   // one total per marker and the common one (packed exchange)
-        ev = pass_eval<K>(nb, base, cursor_w, in, dpa, dpb, ctl[C_EMA] >= ctl[C_SCRMIN], inv2sige, nm1, G, smem, tab, tb, prob, acum_v, muk, logl);
+        ev = pass_eval<K>(nb, base, 0, cursor_w, in, dpa, dpb, ctl[C_EMA] >= ctl[C_SCRMIN], inv2sige, nm1, G, smem, tab, tb, prob, acum_v, muk, logl);
     }
     if (lane == 0) s_res[wave] = (mine && ev.s < ev.nbp) ? ev.s : -1;
     lds_barrier();                                                       // every pass has reported
@@ -1124,6 +1148,183 @@ __device__ __forceinline__ void long_batch_other_k(int K, int nb, int wave, bool
         case 6: long_batch_k<6>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
         case 7: long_batch_k<7>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
         default: long_batch_k<8>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+    }
+}
+
+// ---- ... and the same walk when it may cross stops (the long-batch kernel with continuation) ---------------------------
+// A marker whose effect is non-zero always stops the walk, its position is known in advance, and compute_publish has made its
+// genotype values a plane of operand B: the exchange then also carries G = sum a_j a_s for every marker j behind such a stop s.
+// When the first stop of the parallel evaluation IS that marker, the round does not end: its wavefront records the update and
+// its values (XRec, LDS), every wavefront patches the exact sums of its markers behind the stop --
+//     sum a_j eps += alpha_ G_js + beta_ X_j        sum eps += alpha_ X_s + beta_ nonas        (grid units, integers)
+// (X = mave * nonas, the marker's sum of genotype values: the layout without missing genotypes) -- and the positions behind the
+// stop are evaluated again, in parallel as before, from the stream position the stopping marker left.  Same operations on the
+// same values as walk_piece<.., CK = 1>: the same chain, bit for bit.  The exact sums arrive as (h, l) (put_total_x).
+struct XRec { long long ai, bi, xs; int at, q, cur, rem; };     // the crossed stop: update values in grid units, its X; position, which of the batch's
+                                                                // registered stops, stream position behind it, draws left in its pass behind it
+static_assert(sizeof(XRec) <= 64, "XRec lives in the reducer scratch (L_RED)");
+template <int K>
+__device__ __forceinline__ void pass_commit_x(const PassEval& ev, bool winner, int nb, int base, const LaneIn& in, const LaneTab<K>& tb,
+                                              double prob, double acum_v, const double (&muk)[K], const double (&logl)[K],
+                                              double sigmae, double nm1, const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16, char* smem,
+                                              int nupd, int ncross, int ns, int ps0, int ps1) {
+    const int lane = threadIdx.x & 63;
+    int* ctl = reinterpret_cast<int*>(smem + L_CTL);
+    int* s_cass = reinterpret_cast<int*>(smem + l_cass);
+    const int s = ev.s;
+    const int upto = winner ? s : ev.nbp;
+    if (ev.active && lane < upto) {
+        if (ev.sig0) {
+            if (writer) out.betas_out[in.m] = 0.0;
+        } else if (writer) {                                         // component 0, effect stays 0
+            out.betas_out[in.m] = 0.0; out.comp[in.m] = 0;
+            atomicAdd(&s_cass[in.g * K + 0], 1);
+        }
+    }
+    if (!winner) return;                                             // (uniform)
+    const UpdList ul = upd_list(smem);
+    int kc = 0;
+    double acum2 = acum_v, muk_c = 0.0, denom_c = 1.0;
+    const bool need_search = __builtin_amdgcn_readlane((int)!(prob <= acum_v), s) != 0;   // wave-uniform
+    if (need_search) {
+        decide_rest_wave<K>(s, prob, acum_v, logl, kc, acum2);
+        if (lane == s) {
+#pragma unroll
+            for (int i = 1; i < K; i++)
+                if (i == kc) { muk_c = muk[i]; denom_c = tb.denom[i]; }
+        }
+    }
+    if (lane == s) {
+        LdsStream rs{reinterpret_cast<const uint32_t*>(smem + L_RNG0), reinterpret_cast<const uint32_t*>(smem + L_RNG1),
+                     ev.cursor0 + ev.prefix + 1, &ctl[C_RNGERR]};
+        double beta_new = 0.0;
+        if (kc > 0) beta_new = norm_lx(rs, muk_c, sigmae / denom_c, (TabLds)reinterpret_cast<const double*>(smem + L_ZNX));   // bayes.cpp:455
+        const double dbeta = in.beta_old - beta_new;                 // bayes.cpp:479
+        int upd = 0;
+        double alpha_ = 0.0, beta_ = 0.0;
+        if (fabs(dbeta) > 0.0) {                                     // bayes.cpp:483, phenotype.cpp:328-329,388
+            upd = 1;
+            update_values(dbeta, in.mave, in.msig, alpha_, beta_);
+            const double v1 = beta_ + alpha_;
+            double* uv = ul.val + 4 * nupd;
+            uv[0] = beta_; uv[1] = v1; uv[2] = v1 + alpha_; uv[3] = 0.0;
+            ul.pos[nupd] = base + s;
+        }
+        if (writer) {
+            out.betas_out[in.m] = beta_new; out.comp[in.m] = kc;
+            atomicAdd(&s_cass[in.g * K + kc], 1);
+        }
+        const int cur_s = rs.cursor;
+        const int at = base + s;
+        const int q = (ns > 0 && at == ps0) ? 0 : ((ns > 1 && at == ps1) ? 1 : -1);
+        // (|values| >= 2^10 would not fit the integers of the patch; they put the residual out of range anyway: error 4 in phase C)
+        if (q >= 0 && upd && at + 1 < nb && fabs(alpha_) < 1024.0 && fabs(beta_) < 1024.0) {
+            XRec* xr = reinterpret_cast<XRec*>(smem + L_RED);
+            xr->ai = (long long)(alpha_ * GRID_INV); xr->bi = (long long)(beta_ * GRID_INV);
+            xr->xs = (long long)__builtin_rint(in.mave * (nm1 + 1.0));
+            xr->at = at; xr->q = q; xr->cur = cur_s;
+            xr->rem = s < 63 ? __popcll(ev.use_mask >> (s + 1)) : 0;
+            ctl[C_XFLAG] = 1;
+        } else {
+            const bool planned = in.beta_old != 0.0;
+            ctl[C_XFLAG] = 0;
+            ctl[C_UPD] = nupd + upd;
+            ctl[C_SUPD] = ncross;
+            ctl[C_CURSOR] = cur_s;
+            ctl[C_NDONE] = at + 1;
+            ctl[C_PLN] = (upd && planned) ? 1 : 0;
+            if (!(upd && planned)) {                                 // next batch size from the recent run length (sample_batch_body)
+                const int run = at + 1;
+                const int ema = (3 * ctl[C_EMA] + 16 * run) / 4;
+                ctl[C_EMA] = ema;
+                const int want = nbf16 * ema / 256;
+                int nxt = 16;
+                while (nxt < want && nxt < bmax_) nxt *= 2;
+                ctl[C_NBNEXT] = nxt > bmax_ ? bmax_ : nxt;
+            }
+        }
+    }
+}
+template <int K, class TP>
+__device__ __forceinline__ void long_cont_body(int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const long long* s_toth, const int* s_totl,
+                                               int* s_res, double sigmae, double inv2sige, double nm1, int G, char* smem, TP tab,
+                                               const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16, int ns, int ps0, int ps1) {
+    const int lane = threadIdx.x & 63;
+    int* ctl = reinterpret_cast<int*>(smem + L_CTL);
+    const int base = 64 * wave;
+    const int nbp = nb - base < 0 ? 0 : (nb - base < 64 ? nb - base : 64);
+    const bool screen_on = ctl[C_EMA] >= ctl[C_SCRMIN];
+    __int128 sm = 0, sq = 0;                                         // this lane's marker: sum a eps; the common sum of eps (grid units)
+    long long xm = 0;
+    if (mine) {
+        const int pc = base + lane < nb ? base + lane : 0;
+        sm = ((__int128)s_toth[pc] << 22) + (__int128)s_totl[pc];
+        sq = ((__int128)s_toth[nb] << 22) + (__int128)s_totl[nb];
+        xm = (long long)__builtin_rint(in.mave * (nm1 + 1.0));
+    }
+    int from = 0, cursor0 = cursor_w, nupd = 0, ncross = 0;
+#pragma unroll 1
+    for (;;) {                                                       // (the same number of turns in every wavefront)
+        const int lo = from > base ? from - base : 0;
+        const bool act_w = mine && lo < nbp;                         // this wavefront holds positions the walk has not passed
+        PassEval ev{0, 0, 0, 0, 0, false, false, 0ull};
+        LaneTab<K> tb{};
+        double prob = 0.0, acum_v = 1.0, muk[K], logl[K];
+#pragma unroll
+        for (int i = 0; i < K; i++) { muk[i] = 0.0; logl[i] = 0.0; }
+        if (act_w) {
+            double t0, t1, t2, t3;
+            exact_split(sm, t0, t1);
+            exact_split(sq, t2, t3);
+            ev = pass_eval<K>(nb, base, lo, cursor0, in, t0 + t1, t2 + t3, screen_on, inv2sige, nm1, G, smem, tab, tb, prob, acum_v, muk, logl);
+        }
+        if (lane == 0) { s_res[wave] = (act_w && ev.s < ev.nbp) ? ev.s : -1; s_res[4 + wave] = act_w ? ev.ndraw : 0; }
+        lds_barrier();                                               // every pass has reported
+        const int r0 = s_res[0], r1 = s_res[1], r2 = s_res[2], r3 = s_res[3];
+        const int nd1 = s_res[5], nd2 = s_res[6];                    // (read now: the next turn overwrites them)
+        const int wstop = r0 >= 0 ? 0 : (r1 >= 0 ? 1 : (r2 >= 0 ? 2 : (r3 >= 0 ? 3 : 4)));
+        if (act_w && wave <= wstop)
+            pass_commit_x<K>(ev, wave == wstop, nb, base, in, tb, prob, acum_v, muk, logl, sigmae, nm1, out, writer, l_cass, bmax_, nbf16, smem,
+                             nupd, ncross, ns, ps0, ps1);
+        if (okw && wstop == 4 && wave == ((nb - 1) >> 6)) {          // nobody stopped: the wavefront of the last pass closes the round
+            pass_close_no_stop(ev, nb, bmax_, nbf16, smem);
+            if (lane == 0) { ctl[C_UPD] = nupd; ctl[C_SUPD] = ncross; }
+        }
+        if (wstop == 4) break;                                       // (uniform)
+        lds_barrier();                                               // the stopping marker's wavefront has said how the round goes on
+        if (!ctl[C_XFLAG]) break;                                    // (uniform)
+        const XRec x = *reinterpret_cast<const XRec*>(smem + L_RED);
+        const int p = base + lane;
+        if (mine && p > x.at && p < nb) {
+            const long long hg = s_toth[nb + 1 + p - ps0 - 1];
+            const long long g = x.q ? (hg >> 24) : (hg & 0xFFFFFFll);
+            sm += (__int128)x.ai * g + (__int128)x.bi * xm;
+        }
+        sq += (__int128)x.ai * x.xs + (__int128)x.bi * (long long)(nm1 + 1.0);
+        from = x.at + 1; nupd++; ncross++;
+        const int wa = x.at >> 6;
+        cursor0 = x.cur;
+        if (wave > wa) cursor0 += x.rem + ((wa < 1 && wave > 1) ? nd1 : 0) + ((wa < 2 && wave > 2) ? nd2 : 0);
+    }
+}
+template <int K, class TP>
+__device__ __noinline__ void long_cont_k(int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const long long* s_toth, const int* s_totl,
+                                         int* s_res, double sigmae, double inv2sige, double nm1, int G, char* smem, TP tab,
+                                         const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16, int ns, int ps0, int ps1) {
+    long_cont_body<K>(nb, wave, mine, okw, cursor_w, in, s_toth, s_totl, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16, ns, ps0, ps1);
+}
+template <class TP>
+__device__ __forceinline__ void long_cont_other_k(int K, int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const long long* s_toth, const int* s_totl,
+                                                  int* s_res, double sigmae, double inv2sige, double nm1, int G, char* smem, TP tab,
+                                                  const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16, int ns, int ps0, int ps1) {
+    const LaneIn lc = in;                                                // (by address: hand over a copy, the kernel's own stays in registers)
+    switch (K) {
+        case 2: long_cont_k<2>(nb, wave, mine, okw, cursor_w, lc, s_toth, s_totl, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16, ns, ps0, ps1); break;
+        case 3: long_cont_k<3>(nb, wave, mine, okw, cursor_w, lc, s_toth, s_totl, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16, ns, ps0, ps1); break;
+        case 5: long_cont_k<5>(nb, wave, mine, okw, cursor_w, lc, s_toth, s_totl, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16, ns, ps0, ps1); break;
+        case 6: long_cont_k<6>(nb, wave, mine, okw, cursor_w, lc, s_toth, s_totl, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16, ns, ps0, ps1); break;
+        case 7: long_cont_k<7>(nb, wave, mine, okw, cursor_w, lc, s_toth, s_totl, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16, ns, ps0, ps1); break;
+        default: long_cont_k<8>(nb, wave, mine, okw, cursor_w, lc, s_toth, s_totl, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16, ns, ps0, ps1); break;
     }
 }
 
@@ -1196,6 +1397,43 @@ __device__ __forceinline__ bool poll_totals(int nb, int nv, unsigned long long d
         }
     }
     tot0 = t0; tot1 = t1;
+    return !__any(bad);
+}
+
+// The same for the exact totals of the long-batch kernel that crosses stops (put_total_x): h parked where the other kernels park
+// their doubles (L_TOT), l in the first half of L_SUM (unused in the long-batch kernels: they publish from the tile pass).
+__device__ __forceinline__ bool poll_totals_x(int nv, const unsigned long long* Ttg, unsigned tag24, char* smem, unsigned* abort_word, unsigned long long spin_limit) {
+    const int lane = threadIdx.x & 63;
+    long long* s_toth = reinterpret_cast<long long*>(smem + L_TOT);
+    int* s_totl = reinterpret_cast<int*>(smem + L_SUM);
+    Spin sp;
+    sp.start(spin_limit);
+    bool bad = false;
+    auto look = [&](auto ng_tag) {
+        constexpr int NG = decltype(ng_tag)::value;
+        u32x4 d[NG];
+        for (;;) {
+            if constexpr (NG == 4) get_row4(Ttg, lane, d);
+            else if constexpr (NG == 6) get_row6(Ttg, lane, d);
+            else get_row8(Ttg, lane, d);
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < NG; k++)
+                if (64 * k + lane < nv) ok &= ((d[k].y >> 8) == tag24 && (d[k].w >> 8) == tag24);
+            if (__all(ok)) break;
+            if (sp.expired(abort_word)) { bad = true; break; }
+        }
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            long long h; int l;
+            total_x_decode(d[k], h, l);
+            s_toth[64 * k + lane] = h;
+            s_totl[64 * k + lane] = l;
+        }
+    };
+    if (nv <= 256) look(std::integral_constant<int, 4>{});            // (uniform) nothing crossed, or a short batch
+    else if (nv <= 384) look(std::integral_constant<int, 6>{});
+    else look(std::integral_constant<int, 8>{});
     return !__any(bad);
 }
 
@@ -1350,12 +1588,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 // CONT: the walk may cross markers whose effect was non-zero ("continuation", above; fast layout and all-dirty layout).  A kernel
 // of its own: the code it adds costs the rounds that cross nothing ~3 % (register allocation), so the host launches it only for
 // sweeps in which enough markers are in the model for the crossings to pay (capi.cpp, gmrm_sweep_launch).
-template <int R, int MODE, bool CONT>
+template <int R, int MODE, bool CONT, bool LONG>
 __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     static_assert(!CONT || MODE == 0 || MODE == 2, "continuation: the fast layout and the all-dirty layout");
+    static_assert(!LONG || MODE == 0, "long batches: the layout without missing genotypes");
+    static_assert(LONG || CONT || MODE != 0, "the fast layout without crossings is the long-batch kernel");
     constexpr int CK = !CONT ? 0 : (MODE == 0 ? 1 : 2);   // 1: no marker has a missing genotype (among the phenotyped), 2: every marker may
     constexpr bool FAST = MODE == 0;
-    constexpr bool LONGB = MODE == 0 && !CONT;            // batches of up to 240 markers: four passes of the sampling wavefront
+    constexpr bool LONGB = LONG;                          // batches of up to 240 markers: the walk on four wavefronts (with CONT: it crosses stops)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GE = Geo<R>;
     constexpr int NI = 4 * R;                        // individuals per thread
@@ -1366,8 +1606,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // tile in ONE wavefront's registers cannot be
     constexpr int RPER = LONGB ? GE::RPER : 0, NP = LONGB ? GE::NP : 0, NPX = NP ? NP : 1;
     constexpr int PST = GE::PSTRIDE;                 // bytes per digit plane
-    constexpr int BCAP = batch_cap<MODE, CONT>();
+    constexpr int BCAP = batch_cap<LONG>();
     constexpr int NPASS = BCAP > 128 ? 4 : 2;        // groups of 64 batch positions
+    const int bcap_rt = (LONG && a.bcap >= 16 && a.bcap < BCAP) ? a.bcap : BCAP;   // (schedule knob of the long-batch kernels: GMRM_BATCH_CAP)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wg = blockIdx.x;
     const int W = a.W, K = a.K, G = a.G;
     const int NLS = a.nl;                            // LDS tile slots of this launch
@@ -1409,7 +1650,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         ctl[C_RANGE] = 0;
         ctl[C_SCRMIN] = a.screen_min_run16; ctl[C_NSCRT] = 0; ctl[C_NSCR] = 0;
         ctl[C_EMA] = 16 * a.batch_init / 2;
-        ctl[C_NBNEXT] = a.batch_init < 16 ? 16 : (a.batch_init > BCAP ? BCAP : a.batch_init);
+        ctl[C_NBNEXT] = a.batch_init < 16 ? 16 : (a.batch_init > bcap_rt ? bcap_rt : a.batch_init);
     }
     __syncthreads();
     block_advance(s_rng0, s_rng1, ctl, false);       // S1 = twist(S0)
@@ -1477,8 +1718,14 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     unsigned long long pa[5] = {0, 0, 0, 0, 0};      // phase A: entry barrier, scan + inputs, tiles, exit barrier, publish
     unsigned long long tlast = __builtin_amdgcn_s_memrealtime();
 #define PA(i) do { if (tid == GM_PROF_TID) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); pa[i] += t_ - tpa; tpa = t_; } } while (0)
+    unsigned long long pt[3] = {0, 0, 0};            // "loop top -> barrier" taken apart: end of the round before (meta commit), batch bookkeeping, wait for the tile loads
+    unsigned long long tpt = tlast;
+#define PT(i) do { if (tid == GM_PROF_TID) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); pt[i] += t_ - tpt; tpt = t_; } } while (0)
+#define PT_FROM_LAST() do { tpt = tlast; } while (0)
 #else
 #define PA(i) do { } while (0)
+#define PT(i) do { } while (0)
+#define PT_FROM_LAST() do { } while (0)
 #endif
 
     // ---- the tile window --------------------------------------------------------------------------------
@@ -1820,6 +2067,33 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             // A crossing costs about half a round (the sums behind the marker are patched and decided again, its genotype values
             // become a plane, more values are exchanged): it pays when a good part of the batch lies behind the marker
             const int cross_thr = (b.nb * a.cross + 15) >> 4;   // a.cross: sixteenths of the batch (0: never)
+            if constexpr (LONGB && CONT) {
+                // the long batch: all four groups of 64 positions are scanned; a row per marker behind the first crossed stop always
+                // fits (2 nb <= 480 rows)
+                unsigned long long m2 = 0ull, m3 = 0ull;
+                if (NPASS > 2) { m2 = __ballot(lane + 128 < b.nb && rb2 != 0.0); m3 = __ballot(lane + 192 < b.nb && rb3 != 0.0); }
+                auto pop4 = [&]() __attribute__((always_inline)) -> int {
+                    if (m0) { const int f = __ffsll((long long)m0) - 1; m0 &= m0 - 1ull; return f; }
+                    if (m1) { const int f = 64 + __ffsll((long long)m1) - 1; m1 &= m1 - 1ull; return f; }
+                    if (m2) { const int f = 128 + __ffsll((long long)m2) - 1; m2 &= m2 - 1ull; return f; }
+                    if (m3) { const int f = 192 + __ffsll((long long)m3) - 1; m3 &= m3 - 1ull; return f; }
+                    return -1;
+                };
+                int f0 = pop4();
+                if (f0 < 0) f0 = b.nb;
+                if (a.cross && f0 + 1 < b.nb && f0 + cross_thr <= b.nb - 1) {   // (uniform)
+                    b.ns = 1; b.ps0 = f0;
+                    int last = pop4();                               // the stop that ends the batch, if any
+                    if (NSTOP > 1 && last >= 0 && last + 1 < b.nb && last + cross_thr <= b.nb - 1) {
+                        b.ns = 2; b.ps1 = last; last = pop4();
+                    }
+                    if (last >= 0 && last + 1 < b.nb) b.nb = last + 1;
+                    b.planned = last >= 0 && last < b.nb;
+                } else {
+                    if (f0 + 1 < b.nb) b.nb = f0 + 1;
+                    b.planned = f0 < b.nb;
+                }
+            } else
             if (CONT && a.cross && first + 1 < b.nb && first + cross_thr <= b.nb - 1) {   // (uniform)
                 auto pop_first = [&]() __attribute__((always_inline)) -> int {
                     if (m0) { const int f = __ffsll((long long)m0) - 1; m0 &= m0 - 1ull; return f; }
@@ -2100,6 +2374,16 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                                                              (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx, 0x104, 0xf, 0xf, false));
                             if (n == 0 && in)
                                 put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)m * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu, sx, s2);
+                            if constexpr (CONT) {
+                                // columns 8, 9: G = sum a_j a_s over the slice for the stops s the walk may cross, for the markers behind s only:
+                                // row nb + 1 + (j - ps0 - 1), both stops in one granule pair (column 9 comes to lane 8 through the quad)
+                                if (ns > 0) {              // (uniform)
+                                    const int x9 = __builtin_amdgcn_update_dpp(0, xr, DPP_QUAD_1032, 0xf, 0xf, false);
+                                    if (n == 8 && m > ps0 && m < nb)
+                                        put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)(nb + m - ps0) * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu,
+                                                   (long long)xr, (ns > 1 && m > ps1) ? (long long)x9 : 0ll);
+                                }
+                            }
                         } else if ((n & 3) == 0 && n < 8 && in) put_sum(2 * m + (n >> 2), sx);
                     } else {
                         // a = c - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
@@ -2115,7 +2399,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     }
                     // columns 8, 9: G = sum a_j a_s over the slice for the markers s the walk may cross, kept for the markers behind s
                     // only and packed in one slot (column 9 comes to lane 8 through the quad)
-                    if constexpr (CONT) {
+                    if constexpr (CONT && !LONGB) {
                         if (ns > 0) {                  // (uniform)
                             if constexpr (CK == 1) {
                                 const int x9 = __builtin_amdgcn_update_dpp(0, xr, DPP_QUAD_1032, 0xf, 0xf, false);
@@ -2213,7 +2497,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
         PA(2);
         if constexpr (LONGB) {                        // (published from the tile passes: nothing to collect)
-            b.nv = nb + 1;
+            b.nv = nb + 1 + ((CONT && ns > 0) ? nb - 1 - ps0 : 0);   // behind a crossed stop: one more row per marker (the packed G)
             PA(3);
             PA(4);
             return;
@@ -2281,6 +2565,15 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 // whatever they requested before it, and the two exchange hops are the only stretch of the round in which
                 // nothing else needs them.  They start loading right behind the publish; wavefront 0 reduces and polls.
                 const unsigned tag24 = (b.gen + 1u) & 0xFFFFFFu;
+                // a row's two sums (exact integers as doubles) become its total: one rounding of the exact sum -- or, in the kernel that
+                // crosses stops, the exact sum itself (put_total_x; rows behind nb: the two stops' genotype products, packed)
+                auto put_row = [&](int v, double x1, double x2) __attribute__((always_inline)) {
+                    if constexpr (CONT) {
+                        const long long p1 = (long long)x1, p2 = (long long)x2;
+                        if (v <= b.nb) put_total_x(Tb + 2 * v, tag24, p1 + (p2 >> 22), (unsigned)(p2 & 0x3FFFFFll));
+                        else put_total_x(Tb + 2 * v, tag24, p1 | (p2 << 24), 0u);
+                    } else put_value(Tb + 2 * v, b.gen + 1u, x1 * 0x1p-22 + x2 * GRID);
+                };
                 if (rows > 2) {
                     // far fewer workgroups than rows (N = 50 000: 49 workgroups, up to 241 rows): row after row on one wavefront
                     // is a memory round trip per row; all four wavefronts take granule pairs t, t + 256, ... of the rows x W this
@@ -2302,7 +2595,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                         __hip_atomic_fetch_add(&s_rows[2 * r + 1], x2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     lds_barrier();
-                    for (int r = tid; r < rows; r += SW_TPB) put_value(Tb + 2 * (wg + r * W), b.gen + 1u, s_rows[2 * r] * 0x1p-22 + s_rows[2 * r + 1] * GRID);
+                    for (int r = tid; r < rows; r += SW_TPB) put_row(wg + r * W, s_rows[2 * r], s_rows[2 * r + 1]);
                     lds_barrier();
                     return bad;
                 }
@@ -2322,7 +2615,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     }
                     const double r2 = reduce2(x1, x2);        // lanes 0-31: sum of x1 over the wavefront, lanes 32-63: of x2
                     const double t1 = readlane64(r2, 0), t2 = readlane64(r2, 32);
-                    if (lane == 0) put_value(Tb + 2 * v, b.gen + 1u, t1 * 0x1p-22 + t2 * GRID);
+                    if (lane == 0) put_row(v, t1, t2);
                 }
                 return __any(bad);
             }
@@ -2433,6 +2726,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     __syncthreads();
     while (pos < a.M) {
         TRACE(0);
+        PT(0);
         // ---- the batch: what the run-length estimate asks for, as far as tiles and sampling inputs are on chip
         bool fill_round = false;                      // (uniform) nothing to walk yet: only request tiles (start-up; a walk that ran through a short window)
         {
@@ -2443,6 +2737,17 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             if (!fill_round && mhi - pos < 16 && mhi < a.M) ensure_meta(pos + 64 < a.M ? pos + 64 : a.M);   // (slow path; the refill keeps up in practice)
             if (mhi - pos < have) have = mhi - pos;
             if (have < nb0) { nb0 = have; n_short++; }
+            // Tiles are 16-aligned order positions and go to wavefront T & 3: a batch that straddles 4 k + 1 tiles gives ONE wavefront
+            // a tile more than the others (64 markers from the middle of a tile: five tiles, a pair pass for wavefront 0, one tile
+            // for the others, who wait at the barrier).  Dropping the last, partial tile -- at most 15 markers, which the walk
+            // seldom reaches -- evens the passes out.
+            if (!LONGB && a.tile_trim) {           // (the long batches: 240 markers are 15 or 16 tiles either way, and measured no gain)
+                const int off = pos & 15, tl = (off + nb0 + 15) >> 4;
+                if (off && tl >= 5 && (tl & 3) == 1) {
+                    const int nbt = 16 * (tl - 1) - off;
+                    if (4 * nbt >= 3 * nb0) nb0 = nbt;
+                }
+            }
             cur.p0 = pos; cur.nb = nb0; cur.gen = gen_next;
         }
         if (fill_round) {
@@ -2451,7 +2756,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             // loads were in flight in between (tools/check_prefetch_regs.py)
             n_short++;
         }
+        PT(1);
         tiles_wait();                                 // the tiles requested a round ago are there (no wait in practice)
+        PT(2);
         if (!fill_round) {
         gen_next++;
         compute_publish(cur, li_cur0, li_cur1);
@@ -2482,7 +2789,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
             const int nbw = cur.nb - 64 * wave;                                  // positions of this wavefront's pass (<= 0: none)
             double* s_tot = reinterpret_cast<double*>(smem + L_TOT);
-            int* s_res = reinterpret_cast<int*>(smem + L_AB);                    // int[4]: every pass's first stop (free in this kernel)
+            int* s_res = reinterpret_cast<int*>(smem + L_AB);                    // int[8]: every pass's first stop, every pass's draws (free in this kernel)
             // draws of the passes in front of mine: one per marker whose group has sigmaG != 0 -- known without the totals
             int cursor_w = ctl[C_CURSOR];
             for (int v = 0; v < wave; v++) {
@@ -2493,7 +2800,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             if (wave == 0) {
                 const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
                 Totals t0{0.0, 0.0, 0.0, 0.0}, t1{0.0, 0.0, 0.0, 0.0};
-                okw = poll_totals<true>(cur.nb, cur.nv, 0ull, 0ull, Tb, cur.gen + 1u, smem, t0, t1, abort_word, spin_limit);
+                if constexpr (CONT) okw = poll_totals_x(cur.nv, Tb, (cur.gen + 1u) & 0xFFFFFFu, smem, abort_word, spin_limit);
+                else okw = poll_totals<true>(cur.nb, cur.nv, 0ull, 0ull, Tb, cur.gen + 1u, smem, t0, t1, abort_word, spin_limit);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the row is in LDS before the word that says so
                 if (lane == 0) *reinterpret_cast<volatile int*>(&ctl[C_TOTF]) = okw ? (int)(cur.gen + 1u) : -1;
                 bad |= !okw;
@@ -2508,10 +2816,18 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             }
             TRACE(3);
             PROF(4);   // wait for the totals
+            if constexpr (CONT) {
+                const long long* s_toth = reinterpret_cast<const long long*>(smem + L_TOT);
+                const int* s_totl = reinterpret_cast<const int*>(smem + L_SUM);
+                if (K == 4) long_cont_body<4>(cur.nb, wave, okw && nbw > 0, okw, cursor_w, li_cur0, s_toth, s_totl, s_res, a.sigmae, a.inv2sige, a.nm1, G, smem, (TabLds)s_tab,
+                                              so, wg == 0, a.lds_cass, bcap_rt, a.nb_factor16, cur.ns, cur.ps0, cur.ps1);
+                else long_cont_other_k(K, cur.nb, wave, okw && nbw > 0, okw, cursor_w, li_cur0, s_toth, s_totl, s_res, a.sigmae, a.inv2sige, a.nm1, G, smem, (TabLds)s_tab,
+                                       so, wg == 0, a.lds_cass, bcap_rt, a.nb_factor16, cur.ns, cur.ps0, cur.ps1);
+            } else
             if (K == 4) long_batch_body<4>(cur.nb, wave, okw && nbw > 0, okw, cursor_w, li_cur0, s_tot, s_res, a.sigmae, a.inv2sige, a.nm1, G, smem, (TabLds)s_tab,
-                                           so, wg == 0, a.lds_cass, BCAP, a.nb_factor16);
+                                           so, wg == 0, a.lds_cass, bcap_rt, a.nb_factor16);
             else long_batch_other_k(K, cur.nb, wave, okw && nbw > 0, okw, cursor_w, li_cur0, s_tot, s_res, a.sigmae, a.inv2sige, a.nm1, G, smem, (TabLds)s_tab,
-                                    so, wg == 0, a.lds_cass, BCAP, a.nb_factor16);
+                                    so, wg == 0, a.lds_cass, bcap_rt, a.nb_factor16);
         } else
         if (wave == 0) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
@@ -2586,6 +2902,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         n_batch++;
         TRACE(6);
         PROF(6);   // residual update + plane refresh
+        PT_FROM_LAST();
         meta_commit();
         if (ctl[C_CURSOR] >= 624) block_advance(s_rng0, s_rng1, ctl, true);
     }
@@ -2623,6 +2940,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         for (int i = 0; i < 8; i++) a.stats[(wg == 0 ? 4 : 12) + i] = (long long)prof[i];
         if (wg != 0) for (int i = 0; i < 4; i++) a.stats[20 + i] = (long long)reinterpret_cast<unsigned long long*>(smem + L_M + 64)[i];
         if (wg != 0) for (int i = 0; i < 5; i++) a.stats[24 + i] = (long long)pa[i];
+        if (wg != 0) for (int i = 0; i < 3; i++) a.stats[35 + i] = (long long)pt[i];
     }
 #endif
 }
@@ -2638,27 +2956,33 @@ int sweep_pick_R(size_t stride, int max_wg, int* W_out) {
     return -1;
 }
 
-template <int R, int MODE, bool CONT> static hipError_t launch_RF(const SweepArgs& a0, hipStream_t st, int grid) {
+template <int R, int MODE, bool CONT, bool LONG> static hipError_t launch_RF(const SweepArgs& a0, hipStream_t st, int grid) {
     const int lds = L_TOTAL;
     SweepArgs a = a0;
-    const Carve cv = carve_for<R, CONT, (MODE == 0 && !CONT)>(a.G, a.K);
+    const Carve cv = carve_for<R, CONT, LONG>(a.G, a.K);
     a.lds_cass = cv.cass; a.lds_tab = cv.tab; a.lds_pln = cv.pln; a.lds_ring = cv.ring; a.nl = cv.nl; a.nl_magic = cv.nl_magic; a.win = cv.win;
     if (cv.win < 4) return hipErrorInvalidValue;     // (cannot happen for G <= 64, K <= 8: the tables leave room for several tiles)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, MODE, CONT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, MODE, CONT, LONG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_sweep<R, MODE, CONT>), dim3(grid), dim3(SW_TPB), lds, st, a);
+    hipLaunchKernelGGL((k_sweep<R, MODE, CONT, LONG>), dim3(grid), dim3(SW_TPB), lds, st, a);
     return hipGetLastError();
 }
 #ifdef GM_ONE_KERNEL
-// experiments on code generation (tools/one_kernel.sh): only k_sweep<2, 0, false> is instantiated -- not a product build
-hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) { return launch_RF<2, 0, false>(a, st, grid); }
+// experiments on code generation (tools/one_kernel.sh): only one k_sweep is instantiated -- not a product build
+#ifdef GM_ONE_KERNEL_CONT
+hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) { return launch_RF<2, 0, true, true>(a, st, grid); }
+#else
+hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) { return launch_RF<2, 0, false, true>(a, st, grid); }
+#endif
 hipError_t sweep_occupancy(int, int* blocks_per_cu) { *blocks_per_cu = 1; return hipSuccess; }
 #else
 template <int R> static hipError_t launch_R(const SweepArgs& a, hipStream_t st, int grid) {
     switch (a.miss_mode) {
-        case 0: return a.cross > 0 ? launch_RF<R, 0, true>(a, st, grid) : launch_RF<R, 0, false>(a, st, grid);
-        case 2: return a.cross > 0 ? launch_RF<R, 2, true>(a, st, grid) : launch_RF<R, 2, false>(a, st, grid);
-        default: return launch_RF<R, 1, false>(a, st, grid);
+        case 0:
+            if (a.cross > 0) return a.long_cross ? launch_RF<R, 0, true, true>(a, st, grid) : launch_RF<R, 0, true, false>(a, st, grid);
+            return launch_RF<R, 0, false, true>(a, st, grid);
+        case 2: return a.cross > 0 ? launch_RF<R, 2, true, false>(a, st, grid) : launch_RF<R, 2, false, false>(a, st, grid);
+        default: return launch_RF<R, 1, false, false>(a, st, grid);
     }
 }
 
@@ -2679,13 +3003,13 @@ hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) {
 template <int R> static hipError_t occupancy_R(int* out) {
     const int lds = L_TOTAL;
     int n0 = 0, n1 = 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, 0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep<R, 1, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_sweep<R, 0, true>, SW_TPB, (size_t)lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n0, k_sweep<R, 0, true, false>, SW_TPB, (size_t)lds);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_sweep<R, 1, false>, SW_TPB, (size_t)lds);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_sweep<R, 1, false, false>, SW_TPB, (size_t)lds);
     if (e != hipSuccess) return e;
     *out = n0 < n1 ? n0 : n1;
     return hipSuccess;

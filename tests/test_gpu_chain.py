@@ -77,6 +77,28 @@ def test_screened_sampling_path_is_the_oracle_chain(gpu, monkeypatch, name):
         cases.assert_same_history(got, ref, exact=False, rtol=1e-6)
 
 
+@pytest.mark.parametrize("N,M,env", [(20_000, 6_000, dict(GMRM_SWEEP_R="2")), (20_000, 6_000, dict()),
+                                     (250_000, 2_500, dict(GMRM_NB_FACTOR16="256")), (250_000, 2_500, dict(GMRM_SWEEP_R="2", GMRM_NB_FACTOR16="256"))])
+def test_long_batch_kernel_crosses_stops_and_is_the_oracle_chain(gpu, monkeypatch, N, M, env):
+    """Round 4, GMRM_LONG_CROSS=1: in sparse models without missing genotypes the sweep runs on the long-batch kernel that crosses
+    stops (sweep.hip, long_cont_body): batches of up to 240 markers walked by four wavefronts in parallel, the exact sums exchanged, the sums behind a
+    crossed marker patched with its genotype products and decided again.  A phenotype with a few causal markers (they stay in
+    the model: stops known in advance) on independent genotypes; few (N = 20 000: the reducers' many-rows path) and many
+    workgroups (N = 250 000: one or two rows per reducer, on wavefront 0), with and without register-home tiles (R = 2 / R = 1)."""
+    monkeypatch.setenv("GMRM_LONG_CROSS", "1")                          # (not the default: measured slower, DESIGN.md section 9)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case = cases.Case("lcross", N, M, 1, 4, 1, 0.0, 60, 4711, 8 if N < 100_000 else 5, 12)
+    inp = cases.make_inputs(case)
+    got = cases.run_gpu(case, inp)
+    want = cases.run_oracle(case, inp, canon=True)
+    cases.assert_same_history(got, want, exact=True)
+    h = got[0]
+    print("updates per sweep", h["nupd"], "rounds", h["nbatch"], "crossed stops", h["ncross"])
+    assert sum(h["ncross"][2:]) > 0, h["ncross"]                       # (the first sweeps may run on the dense model's kernel)
+    assert h["nbatch"][-1] < M // 20                                   # long batches
+
+
 @pytest.mark.parametrize("name,k", [("small", 1), ("small", 37), ("ragged", 64), ("groups", 200), ("groups", 512)])
 def test_sweep_in_parts_is_the_same_chain(gpu, name, k):
     """gmrm_sampler_begin_parts / _launch_part / _finish_part (the building block of `--sync-every k`): one shard that cuts
@@ -306,11 +328,15 @@ def test_long_chain_stays_bit_exact(gpu):
 
 @pytest.mark.parametrize("env", [dict(GMRM_SWEEP_R="2"), dict(GMRM_SWEEP_R="4"),
                                  dict(GMRM_REDUCE_W0="1"), dict(GMRM_REDUCE_W0="1", GMRM_NB_FACTOR16="64", GMRM_SWEEP_R="2"),
-                                 dict(GMRM_NB_FACTOR16="8"), dict(GMRM_NB_FACTOR16="256", GMRM_SWEEP_R="2", GMRM_NO_CROSS="1")])
+                                 dict(GMRM_NB_FACTOR16="8"), dict(GMRM_NB_FACTOR16="256", GMRM_SWEEP_R="2", GMRM_NO_CROSS="1"),
+                                 dict(GMRM_LONG_CROSS="2", GMRM_LONG_CROSS_FRAC16="1", GMRM_NB_FACTOR16="256", GMRM_SWEEP_R="2"),
+                                 dict(GMRM_LONG_CROSS="2", GMRM_LONG_CROSS_FRAC16="4", GMRM_NB_FACTOR16="64", GMRM_SWEEP_R="4"),
+                                 dict(GMRM_LONG_CROSS="2", GMRM_LONG_CROSS_FRAC16="1", GMRM_NB_FACTOR16="256")])
 def test_kernel_geometries_and_schedules_give_the_same_chain(gpu, monkeypatch, env):
     """The results may not depend on how the kernel is laid out or scheduled: bytes per thread
     R = 1 / 2 / 4 (slice width, tile window, register-home tiles at R = 2 / 4, batch cap), who takes the reduce role,
-    larger and smaller batches (up to the 240-marker cap of the long-batch kernel, kept on it by GMRM_NO_CROSS).
+    larger and smaller batches (up to the 240-marker cap of the long-batch kernel, kept on it by GMRM_NO_CROSS); the long-batch
+    kernel that crosses stops (GMRM_LONG_CROSS=2: in dense models as well) with crossings wherever a marker lies behind the stop.
     Cases: no missing genotypes (2-value exchange layout, packed partial sums) and 5 % missing (4-value layout)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)

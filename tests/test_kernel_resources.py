@@ -34,7 +34,7 @@ def test_kernel_resources_match_the_committed_baseline():
 def test_resource_guard_catches_regressions():
     """Negative controls: spills, scratch, SGPR spills +10 %, code +15 %, a vanished instantiation."""
     kr = _tool()
-    k = "void gm::k_sweep<2, 0, false>(gm::SweepArgs)"
+    k = "void gm::k_sweep<2, 0, false, true>(gm::SweepArgs)"
     base = {k: dict(vgpr_count=496, agpr_count=240, sgpr_count=106, sgpr_spill_count=300, vgpr_spill_count=0,
                     private_segment_fixed_size=0, group_segment_fixed_size=0, code_bytes=60000)}
     assert kr.compare(base, base) == []

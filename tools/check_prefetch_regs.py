@@ -44,7 +44,7 @@ def agprs(text):
 def kernels(asm):
     cur, name = None, None
     for ln in asm.splitlines():
-        m = re.match(r"^(_ZN2gm7k_sweepILi\d+ELi\d+ELb[01]EEEvNS_9SweepArgsE):", ln)
+        m = re.match(r"^(_ZN2gm7k_sweepILi\d+ELi\d+ELb[01]ELb[01]EEEvNS_9SweepArgsE):", ln)
         if m:
             name, cur = m.group(1), []
             continue
@@ -152,8 +152,8 @@ def check_kernel(name, lines):
         if s.startswith("global_load_dwordx4 a["):
             pf |= agprs(s.split(",")[0])
     if not pf:
-        # register-home tiles exist only in the long-batch kernels (two-value layout, nothing crossed) at R = 2 and R = 4
-        if re.search(r"k_sweepILi[24]ELi0ELb0E", name):
+        # register-home tiles exist only in the long-batch kernels (the layout without missing genotypes; last template argument) at R = 2 and R = 4
+        if re.search(r"k_sweepILi[24]ELi0ELb[01]ELb1E", name):
             return [f"{name}: no AGPR tile loads found (did the kernel change?)"]
         print(f"ok  {name}: no register-home tiles in this kernel (every tile lives in LDS)")
         return []
