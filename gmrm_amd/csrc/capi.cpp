@@ -765,6 +765,12 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.P = tr.P; a.Tt = tr.Tt; a.cnt = tr.cnt;
     a.batch_init = c->batch_init;
     a.bcap = c->batch_cap;
+    // wavefront 0 waits before its first look at the totals (sweep.hip): measured optima on 500k x 1M (245 workgroups): 45 units of
+    // 64 clocks for the long-batch kernel, 15 for the others; two chains of 123 workgroups: 25; 50k x 100k (49 workgroups): 20 and 0
+    // (profiles/r04_ab_totals_delay.txt; GMRM_TOTALS_DELAY / GMRM_TOTALS_DELAY2 override)
+    a.totals_delay = c->W >= 200 ? 45 : (c->W >= 100 ? 25 : 20); a.totals_delay2 = c->W >= 100 ? 15 : 0;
+    if (const char* e = std::getenv("GMRM_TOTALS_DELAY")) a.totals_delay = std::atoi(e) & 127;
+    if (const char* e = std::getenv("GMRM_TOTALS_DELAY2")) a.totals_delay2 = std::atoi(e) & 127;
     a.tile_trim = std::getenv("GMRM_NO_TILE_TRIM") ? 0 : 1;         // A/B knob (sweep.hip, the batch at the top of a round)
     a.trace = nullptr;
     if (std::getenv("GMRM_SWEEP_TRACE")) {                  // diagnostic build only
@@ -915,6 +921,8 @@ int gmrm_sweep_finish(gmrm_ctx* c, int t, gmrm_sweep_out* out) {
                          st[27] * 0.01 / (double)st[1], st[28] * 0.01 / (double)st[1], st[2]);
             std::fprintf(stderr, "[sweep prof loop top wg W/2] meta commit %.2fus batch bookkeeping %.2fus wait for tile loads %.2fus (the rest of 'loop top -> barrier' is the barrier)\n",
                          st[35] * 0.01 / (double)st[1], st[36] * 0.01 / (double)st[1], st[37] * 0.01 / (double)st[1]);
+            std::fprintf(stderr, "[sweep prof polls wg W/2] looks per round: %.2f at the row of partial sums (reduce role, wavefront 0), %.2f at the totals\n",
+                         st[38] / (double)st[1], st[39] / (double)st[1]);
         }
         if (out->cass) std::memcpy(out->cass, hc.data(), sizeof(int) * (size_t)tr.G * tr.K);
         HIPCHK(hipMemcpy(out->rng_state, tr.rng_state, 624 * sizeof(uint32_t), hipMemcpyDeviceToHost));

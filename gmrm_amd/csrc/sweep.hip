@@ -1343,7 +1343,7 @@ __device__ __forceinline__ bool dirty_at(unsigned long long dm0, unsigned long l
 template <bool PACKED>
 __device__ __forceinline__ bool poll_totals(int nb, int nv, unsigned long long dm0, unsigned long long dm1,
                                             const unsigned long long* Ttg, unsigned tag, char* smem,
-                                            Totals& tot0, Totals& tot1, unsigned* abort_word, unsigned long long spin_limit) {
+                                            Totals& tot0, Totals& tot1, unsigned* abort_word, unsigned long long spin_limit, int& nlooks) {
     const int lane = threadIdx.x & 63;
     double* s_tot = reinterpret_cast<double*>(smem + L_TOT);
     Spin sp;
@@ -1353,6 +1353,10 @@ __device__ __forceinline__ bool poll_totals(int nb, int nv, unsigned long long d
         constexpr int NG = decltype(ng_tag)::value;
         u32x4 d[NG];
         for (;;) {
+            nlooks++;
+#ifdef GM_SWEEP_PROF
+            if (lane == 0) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[5]++;      // looks at the totals
+#endif
             if constexpr (NG == 4) get_row4(Ttg, lane, d);
             else if constexpr (NG == 6) get_row6(Ttg, lane, d);
             else get_row8(Ttg, lane, d);
@@ -1413,6 +1417,9 @@ __device__ __forceinline__ bool poll_totals_x(int nv, const unsigned long long* 
         constexpr int NG = decltype(ng_tag)::value;
         u32x4 d[NG];
         for (;;) {
+#ifdef GM_SWEEP_PROF
+            if (lane == 0) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[5]++;      // looks at the totals
+#endif
             if constexpr (NG == 4) get_row4(Ttg, lane, d);
             else if constexpr (NG == 6) get_row6(Ttg, lane, d);
             else get_row8(Ttg, lane, d);
@@ -2609,6 +2616,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                     Spin sp;
                     sp.start(spin_limit);
                     for (;;) {
+#ifdef GM_SWEEP_PROF
+                        if (lane == 0) reinterpret_cast<unsigned long long*>(smem + L_M + 64)[4]++;      // looks at the row of partial sums
+#endif
                         get_packed4(rowp, lane, tag24, W, x1, x2, got);
                         if (__all(got == want)) break;
                         if (sp.expired(abort_word)) { bad = true; break; }
@@ -2720,6 +2730,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     };
 
     Batch cur{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0};
+    const int tdelay = LONGB ? a.totals_delay : a.totals_delay2;    // wavefront 0: s_sleep units (64 clocks) before the first look at the totals (see there)
     LaneIn li_cur0{0, 0, 0.0, 0.0, 1.0}, li_cur1{0, 0, 0.0, 0.0, 1.0};
     bool bad = false;
     ensure_meta(META_POS < a.M ? META_POS : a.M);
@@ -2800,8 +2811,15 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             if (wave == 0) {
                 const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
                 Totals t0{0.0, 0.0, 0.0, 0.0}, t1{0.0, 0.0, 0.0, 0.0};
+                // The totals cannot be complete before two memory round trips have passed (the other reducers' looks, then mine), and a
+                // look that fails is not free: 245 workgroups looking at the same 4 KB 3.7 times per round slow the round trips of
+                // everybody (measured: a wait of 1.2 us before the first look, -1.7 % on 500k x 1M; two looks in flight, +4 %:
+                // profiles/r04_ab_totals_delay.txt, r04_ab_poll_two_looks.txt).  The host picks the wait from the grid's size.
+                for (int i = 0; i < tdelay; i++) __builtin_amdgcn_s_sleep(1);
+                int nlooks = 0;
                 if constexpr (CONT) okw = poll_totals_x(cur.nv, Tb, (cur.gen + 1u) & 0xFFFFFFu, smem, abort_word, spin_limit);
-                else okw = poll_totals<true>(cur.nb, cur.nv, 0ull, 0ull, Tb, cur.gen + 1u, smem, t0, t1, abort_word, spin_limit);
+                else okw = poll_totals<true>(cur.nb, cur.nv, 0ull, 0ull, Tb, cur.gen + 1u, smem, t0, t1, abort_word, spin_limit, nlooks);
+
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the row is in LDS before the word that says so
                 if (lane == 0) *reinterpret_cast<volatile int*>(&ctl[C_TOTF]) = okw ? (int)(cur.gen + 1u) : -1;
                 bad |= !okw;
@@ -2834,7 +2852,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             const unsigned long long* Tb = Ttg + 2 * (size_t)(cur.gen & 1u) * SW_VMAX;
             Totals tot0{0.0, 0.0, 0.0, 0.0}, tot1{0.0, 0.0, 0.0, 0.0};
             const Draws draws = sample_prepare(cur.nb, smem, (TabLds)s_tab, li_cur0.g, li_cur1.g);
-            const bool okw = poll_totals<LONGB>(cur.nb, cur.nv, cur.dm0, cur.dm1, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word, spin_limit);
+            for (int i = 0; i < tdelay; i++) __builtin_amdgcn_s_sleep(1);               // (as in the long-batch kernel: see there)
+            int nlooks = 0;
+            const bool okw = poll_totals<LONGB>(cur.nb, cur.nv, cur.dm0, cur.dm1, Tb, cur.gen + 1u, smem, tot0, tot1, abort_word, spin_limit, nlooks);
+
             if (lane == 0) *reinterpret_cast<volatile int*>(&ctl[C_TOTF]) = (int)(cur.gen + 1u);   // the loaders may start
             TRACE(3);
             PROF(4);   // wait for the totals
@@ -2941,6 +2962,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         if (wg != 0) for (int i = 0; i < 4; i++) a.stats[20 + i] = (long long)reinterpret_cast<unsigned long long*>(smem + L_M + 64)[i];
         if (wg != 0) for (int i = 0; i < 5; i++) a.stats[24 + i] = (long long)pa[i];
         if (wg != 0) for (int i = 0; i < 3; i++) a.stats[35 + i] = (long long)pt[i];
+        if (wg != 0) for (int i = 0; i < 2; i++) a.stats[38 + i] = (long long)reinterpret_cast<unsigned long long*>(smem + L_M + 64)[4 + i];
     }
 #endif
 }
