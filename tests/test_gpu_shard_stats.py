@@ -94,7 +94,7 @@ def test_sharded_schedule_samples_the_same_posterior_within_mc_error(gpu):
 def test_eight_shards_and_the_exchange_period(gpu):
     """BASELINE's partition is 8 marker shards.  With one residual exchange per sweep every shard absorbs the phenotype on its
     own for a whole sweep: the fraction of visits that change an effect grows with the number of shards (DESIGN.md section 6:
-    the reason the predicted 8-GPU efficiency is 0.53), and markers in different shards can hold the same signal for a sweep.
+    the reason the predicted 8-GPU efficiency is 0.52), and markers in different shards can hold the same signal for a sweep.
     `--sync-every k` reconciles the replicas every k markers of a block.  This test runs 8 shards with k = a whole block (once
     per sweep), a quarter and a sixteenth of a block against the 1-shard chain on a phenotype with signal, requires every one
     of them to agree with the sequential chain within Monte-Carlo error, and records update fraction and agreement per k
