@@ -765,6 +765,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.P = tr.P; a.Tt = tr.Tt; a.cnt = tr.cnt;
     a.batch_init = c->batch_init;
     a.bcap = c->batch_cap;
+    a.direct_pub = std::getenv("GMRM_NO_DIRECT_PUBLISH") ? 0 : 1;   // A/B knob
     // wavefront 0 waits before its first look at the totals (sweep.hip): measured optima on 500k x 1M (245 workgroups): 45 units of
     // 64 clocks for the long-batch kernel, 15 for the others; two chains of 123 workgroups: 25; 50k x 100k (49 workgroups): 20 and 0
     // (profiles/r04_ab_totals_delay.txt; GMRM_TOTALS_DELAY / GMRM_TOTALS_DELAY2 override)

@@ -49,6 +49,7 @@ struct SweepArgs {
     int batch_init;
     int totals_delay;              // long-batch kernel: s_sleep units (64 clocks) before wavefront 0's first look at the totals
     int totals_delay2;             // ... the same in the other kernels
+    int direct_pub;                // short-batch kernels: a batch of four tiles or more publishes its packed rows from the tile passes (A/B knob)
     int tile_trim;                 // 1: a batch that would give one wavefront a tile more than the others drops its last, partial tile
     int bcap;                      // long-batch kernels: longest batch (0: the kernel's own cap; env GMRM_BATCH_CAP)
     unsigned long long* trace;     // diagnostic build: [W][64][8] wall-clock stamps of rounds 2000..2063, or null

@@ -61,6 +61,10 @@
 
 namespace gm {
 
+#ifndef GM_PACK_ROWS
+#define GM_PACK_ROWS 1            // 0: the kernels other than the long-batch ones exchange one value per granule pair (rounds 1-3; A/B builds)
+#endif
+
 // ---- geometry per R (bytes of a column per thread) -------------------------------------------
 template <int R> struct Geo {
     static constexpr int SB = SW_TPB * R;                 // slice bytes per workgroup (= genotype bytes = plane records)
@@ -2002,7 +2006,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // ---- the marker loop ---------------------------------------------------------------------------------
     // Generation g uses tag g+1 and buffer g&1; a buffer is rewritten only after every
     // workgroup has sampled the generation that used it.
-    struct Batch { int p0, nb, nv; unsigned gen; bool planned; unsigned long long dm0, dm1; int ns, ps0, ps1; };   // planned: ends at a marker known to stop the walk; dm: dirty positions;
+    struct Batch { int p0, nb, nv; unsigned gen; bool planned; unsigned long long dm0, dm1; int ns, ps0, ps1; int nr; };   // nv: totals the walk waits for; nr: rows of partial sums the reducers sum   // planned: ends at a marker known to stop the walk; dm: dirty positions;
                                                                                                                 // ns, ps: the markers with a non-zero effect the walk may cross (batch positions)
     unsigned gen_next = 0;
     long long n_upd = 0, n_batch = 0, n_planned = 0, n_stale = 0, n_fastb = 0, n_cross = 0, n_short = 0;
@@ -2268,6 +2272,29 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         // operand B: columns 0..6 = the digit planes, 8 and 9 = the planes of the markers the walk may cross; the others
         // (7, 10..15) read plane 0 and their results are dropped
         const int ncol = lane & 15;
+        const int ntb = ((p0 + nb - 1) >> 4) - (p0 >> 4) + 1;             // tiles of the batch
+        // Packed rows straight from the tile passes (as the long-batch kernel does) when every tile of the batch has ONE owner (four
+        // tiles or more: no split passes meeting in LDS atomics) and nothing is merged in at the publish (the sparse Z terms): no
+        // LDS round trip, no barrier, no publish loop between a wavefront's last MFMA and its partial sums being on their way.
+#if GM_PACK_ROWS
+        const bool direct = !LONGB && a.direct_pub && ntb >= 4 && !(MODE == 1 && sparse_z);       // (uniform)
+#else
+        const bool direct = false;
+#endif
+        const unsigned dtag24 = (b.gen + 1u) & 0xFFFFFFu;
+        const int npair_d = nb + 1 + nd;
+        long long dq1 = 0, dq2 = 0;                                       // this slice's sums of q as grid integers (rows of the dirty markers)
+        if (direct && MODE != 0) {
+            dq1 = (long long)((s_wsq[0] + s_wsq[2] + s_wsq[4] + s_wsq[6]) * 0x1p22);
+            dq2 = (long long)((s_wsq[1] + s_wsq[3] + s_wsq[5] + s_wsq[7]) * GRID_INV);
+        }
+        auto pk_row = [&](int r) __attribute__((always_inline)) -> unsigned long long* {
+            return Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)r * a.Wpad + wg);
+        };
+        auto shl4 = [&](long long v) __attribute__((always_inline)) -> long long {   // the value of lane n + 4 of the row (DPP row_shl:4)
+            return (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_update_dpp(0, (int)(v >> 32), 0x104, 0xf, 0xf, false) << 32) |
+                               (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0xf, false));
+        };
         const int poff = ncol < 7 ? ncol * PST + (ncol >> 2) * 64 : ((CONT && (ncol == 8 || ncol == 9)) ? (ncol - 1) * PST + 64 : 0);
         const uint32_t pb0 = lds_addr(planes + poff + kg * 64);
         constexpr uint32_t M0 = 0x03030303u, M1 = 0x01010101u;
@@ -2391,6 +2418,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                                                    (long long)xr, (ns > 1 && m > ps1) ? (long long)x9 : 0ll);
                                 }
                             }
+                        } else if (direct) {
+                            const long long s2 = shl4(sx);
+                            if (n == 0 && in) put_packed(pk_row(m), dtag24, sx, s2);
                         } else if ((n & 3) == 0 && n < 8 && in) put_sum(2 * m + (n >> 2), sx);
                     } else {
                         // a = c - 3 [missing], b = 1 - [missing]:  sum a d = X - 3 Z,  sum b d = (sum d) - Z; the
@@ -2398,6 +2428,14 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                         // occurs for it only where the residual is 0.)
                         const int zr = zcc0[q][r] + (zcc1[q][r] >> 2) + (zcc2[q][r] >> 4);
                         const long long sz = planes_sum(n == 7 ? 0 : zr);
+                        if (direct) {
+                            const long long va = sx - 3 * sz, va2 = shl4(va), nz2 = shl4(-sz);
+                            if (n == 0 && in) {
+                                put_packed(pk_row(m), dtag24, va, va2);
+                                if (all_dirty || dirty_at(dm0, dm1, m))
+                                    put_packed(pk_row(nb + 1 + (all_dirty ? m : dirty_rank(dm0, dm1, m))), dtag24, dq1 - sz, dq2 + nz2);
+                            }
+                        } else
                         if ((n & 3) == 0 && n < 8 && in) {
                             put_sum(2 * m + (n >> 2), sx - 3 * sz);
                             if (all_dirty || dirty_at(dm0, dm1, m))
@@ -2410,8 +2448,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                         if (ns > 0) {                  // (uniform)
                             if constexpr (CK == 1) {
                                 const int x9 = __builtin_amdgcn_update_dpp(0, xr, DPP_QUAD_1032, 0xf, 0xf, false);
-                                if (n == 8 && m > ps0 && m < nb)
-                                    put_sum(2 * nb + 2 + m - ps0 - 1, (long long)xr + ((ns > 1 && m > ps1) ? ((long long)x9 << 24) : 0ll));
+                                if (n == 8 && m > ps0 && m < nb) {
+                                    if (direct) put_packed(pk_row(npair_d + m - ps0 - 1), dtag24, (long long)xr, (ns > 1 && m > ps1) ? (long long)x9 : 0ll);
+                                    else put_sum(2 * nb + 2 + m - ps0 - 1, (long long)xr + ((ns > 1 && m > ps1) ? ((long long)x9 << 24) : 0ll));
+                                }
                             } else if constexpr (!TF) {
                                 // all-dirty layout: column 8 = a_s, column 9 = b_s of the one stop; per marker behind it
                                 //   slot 0: G_a | G_ab << 26 = sum a_j a_s | sum a_j b_s  (a_j = c - 3 [missing]: X - 3 Z)
@@ -2421,9 +2461,14 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                                 const int ga9 = __builtin_amdgcn_update_dpp(0, ga, DPP_QUAD_1032, 0xf, 0xf, false);
                                 const int zr9 = __builtin_amdgcn_update_dpp(0, zr, DPP_QUAD_1032, 0xf, 0xf, false);
                                 if (n == 8 && m > ps0 && m < nb) {
-                                    const int sl = 4 * nb + 4 + 2 * (m - ps0 - 1);
-                                    put_sum(sl, (long long)ga + ((long long)ga9 << 26));
-                                    put_sum(sl + 1, (long long)zr + ((long long)zr9 << 26));
+                                    if (direct) {
+                                        put_packed(pk_row(npair_d + 1 + 2 * (m - ps0 - 1)), dtag24, (long long)ga, (long long)ga9);
+                                        put_packed(pk_row(npair_d + 2 + 2 * (m - ps0 - 1)), dtag24, (long long)zr, (long long)zr9);
+                                    } else {
+                                        const int sl = 4 * nb + 4 + 2 * (m - ps0 - 1);
+                                        put_sum(sl, (long long)ga + ((long long)ga9 << 26));
+                                        put_sum(sl + 1, (long long)zr + ((long long)zr9 << 26));
+                                    }
                                 }
                             }
                         }
@@ -2467,7 +2512,6 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)nb * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu, p1, p2);
             }
         }
-        const int ntb = ((p0 + nb - 1) >> 4) - (p0 >> 4) + 1;             // tiles of the batch
         if (!LONGB && ntb < 4) {                                          // (uniform; the long-batch kernel publishes whole tiles from the pass itself)
             const int tb0 = p0 >> 4;
             const int tsplit = ntb >= 2 ? 2 : 1, ksplit = 4 / tsplit;     // the 4 wavefronts = tsplit tile groups x ksplit parts of the slice
@@ -2505,15 +2549,84 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         PA(2);
         if constexpr (LONGB) {                        // (published from the tile passes: nothing to collect)
             b.nv = nb + 1 + ((CONT && ns > 0) ? nb - 1 - ps0 : 0);   // behind a crossed stop: one more row per marker (the packed G)
+            b.nr = b.nv;
+            PA(3);
+            PA(4);
+            return;
+        }
+        const int nv0 = 2 * nb + 2 + 2 * nd;
+        // behind a crossed stop: one more value per marker (two, and two for the stop, in the all-dirty layout)
+        const int nv = nv0 + ((CONT && ns > 0) ? (CK == 2 ? 2 + 2 * (nb - 1 - ps0) : nb - 1 - ps0) : 0);
+        if (direct) {                                 // (uniform) the rows left the tile passes; the common row and the stop's own sums follow
+            if (tid == 0)
+                put_packed(pk_row(nb), dtag24, (long long)((s_wsq[0] + s_wsq[2] + s_wsq[4] + s_wsq[6]) * 0x1p22),
+                           (long long)((s_wsq[1] + s_wsq[3] + s_wsq[5] + s_wsq[7]) * GRID_INV));
+            if constexpr (CK == 2) {
+                if (ns > 0 && tid == 64)
+                    put_packed(pk_row(npair_d), dtag24, (s_ab[0] & 0xFFFF) + (s_ab[1] & 0xFFFF) + (s_ab[2] & 0xFFFF) + (s_ab[3] & 0xFFFF),
+                               ((s_ab[0] >> 16) & 0xFFFF) + ((s_ab[1] >> 16) & 0xFFFF) + ((s_ab[2] >> 16) & 0xFFFF) + ((s_ab[3] >> 16) & 0xFFFF));
+            }
+            b.nv = nv;
+            b.nr = npair_d + ((CONT && ns > 0) ? (CK == 2 ? 1 + 2 * (nb - 1 - ps0) : nb - 1 - ps0) : 0);
             PA(3);
             PA(4);
             return;
         }
         lds_barrier();                                // the LDS sums are complete (tile loads stay in flight)
         PA(3);
-        const int nv0 = 2 * nb + 2 + 2 * nd;
-        // behind a crossed stop: one more value per marker (two, and two for the stop, in the all-dirty layout)
-        const int nv = nv0 + ((CONT && ns > 0) ? (CK == 2 ? 2 + 2 * (nb - 1 - ps0) : nb - 1 - ps0) : 0);
+#if GM_PACK_ROWS
+        // Packed rows (round 4, as in the long-batch kernel): the two exact parts of a value -- slots 2 r and 2 r + 1: a marker's
+        // sum, the common sum, a dirty marker's Z -- leave as ONE granule pair (put_packed), so a batch has half the rows and a
+        // reducer seldom more than one; the reducers publish the totals slot by slot as before (reduce_role), the walk does not
+        // notice.  Behind the pairs: the rows of a crossed stop (one per marker behind it with the packed genotype products
+        // split into the two fields; in the all-dirty layout the stop's own sums first, then two rows per marker).
+        const int npair = nb + 1 + nd;                // (2 npair == nv0)
+        const int nxr = (CONT && ns > 0) ? (CK == 2 ? 1 + 2 * (nb - 1 - ps0) : nb - 1 - ps0) : 0;
+        auto val_at = [&](int vi) __attribute__((always_inline)) -> long long {    // the integer of slot vi < nv0 (grid units of its part)
+            if (vi >= 2 * nb && vi < 2 * nb + 2) {    // sum q1, sum q2 over the slice
+                const int w2 = vi - 2 * nb;
+                return (long long)((s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2]) * (w2 ? GRID_INV : 0x1p22));   // exact: multiples of the grids
+            }
+            long long v = s_sum[vi];
+            if constexpr (MODE == 1) {
+                if (sparse_z) {                       // X - 3 Z for the a-sums of a dirty marker, -Z in its own b-slots
+                    if (vi >= 2 * nb + 2) v = -s_zsp[vi - (2 * nb + 2)];
+                    else if (dirty_at(dm0, dm1, vi >> 1)) v -= 3 * s_zsp[2 * dirty_rank(dm0, dm1, vi >> 1) + (vi & 1)];
+                }
+            }
+            if (vi >= 2 * nb + 2) {                  // dirty marker: sum b d = sum d - Z, this slice's sum of the exact part as an integer
+                const int w2 = vi & 1;
+                const double dsum = s_wsq[w2] + s_wsq[2 + w2] + s_wsq[4 + w2] + s_wsq[6 + w2];
+                v += (long long)(dsum * (w2 ? GRID_INV : 0x1p22));
+            }
+            s_sum[vi] = 0;                           // (split passes add into these slots)
+            return v;
+        };
+        for (int r = tid; r < npair + nxr; r += SW_TPB) {
+            long long p1, p2;
+            if (r < npair) { p1 = val_at(2 * r); p2 = val_at(2 * r + 1); }
+            else {
+                const int k = r - npair;
+                if constexpr (CK == 2) {
+                    if (k == 0) {                     // the stop's own sums A_s, B_s: the wavefronts' shares of the plane build
+                        p1 = (s_ab[0] & 0xFFFF) + (s_ab[1] & 0xFFFF) + (s_ab[2] & 0xFFFF) + (s_ab[3] & 0xFFFF);
+                        p2 = ((s_ab[0] >> 16) & 0xFFFF) + ((s_ab[1] >> 16) & 0xFFFF) + ((s_ab[2] >> 16) & 0xFFFF) + ((s_ab[3] >> 16) & 0xFFFF);
+                        s_sum[nv0] = 0; s_sum[nv0 + 1] = 0;
+                    } else {
+                        const long long v = s_sum[nv0 + 1 + k];
+                        s_sum[nv0 + 1 + k] = 0;
+                        p1 = v & 0x3FFFFFFll; p2 = v >> 26;
+                    }
+                } else {
+                    const long long v = s_sum[nv0 + k];
+                    s_sum[nv0 + k] = 0;
+                    p1 = v & 0xFFFFFFll; p2 = v >> 24;
+                }
+            }
+            put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)r * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu, p1, p2);
+        }
+        b.nr = npair + nxr;
+#else
         if constexpr (CONT) {
             if (ns > 0) {                             // (uniform) packed G counts: integers < 2^52, exact as doubles
                 for (int vi = nv0 + tid; vi < nv; vi += SW_TPB) {
@@ -2553,6 +2666,8 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             }
             put_value(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)vi * a.Wpad + wg), b.gen + 1u, tot);
         }
+        b.nr = nv;
+#endif
         b.nv = nv;
         PA(4);
     };
@@ -2560,10 +2675,10 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // reduce role: workgroup v sums row v of generation b.gen over all workgroups
     auto reduce_role = [&](const Batch& b) __attribute__((always_inline)) -> bool {
         bool bad = false;
-        if (wg < b.nv) {
+        if (wg < b.nr) {
             const unsigned long long* Pb = Pg + 2 * (size_t)(b.gen & 1u) * SW_VMAX * a.Wpad;
             unsigned long long* Tb = Ttg + 2 * (size_t)(b.gen & 1u) * SW_VMAX;
-            const int rows = (b.nv - wg + W - 1) / W;         // rows wg, wg + W, ... of this workgroup (uniform)
+            const int rows = (b.nr - wg + W - 1) / W;         // rows wg, wg + W, ... of this workgroup (uniform)
             if constexpr (LONGB) {
                 // packed rows (put_packed): both exact parts of a marker arrive in one granule pair; the reducer sums each part
                 // (exact: any order) and publishes ONE total, the parts added with one rounding -- what the walk did with them.
@@ -2629,8 +2744,69 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 }
                 return __any(bad);
             }
-            // The other kernels keep all four wavefronts in the reduce role (their batches are short, the loads few: measured
-            // c2 22.7 against 23.6 ms, c6 148 against 154, c5 equal); GMRM_REDUCE_W0=1 gives them the division of labour above.
+#if GM_PACK_ROWS
+            // The other kernels: packed rows as well (compute_publish), all four wavefronts in the reduce role (their batches are
+            // short, the loads few: measured c2 22.7 against 23.6 ms, c6 148 against 154, c5 equal with wavefront 0 alone).  A row's
+            // two sums become the totals of the slots the walk reads: 2 r and 2 r + 1 for the pairs, one packed integer for the
+            // rows of a crossed stop.
+            {
+                const unsigned tag24 = (b.gen + 1u) & 0xFFFFFFu;
+                const int nd_ = MODE == 2 ? b.nb : __popcll(b.dm0) + __popcll(b.dm1);
+                const int npair = b.nb + 1 + nd_, nv0 = 2 * npair;
+                auto emit_row = [&](int r, double x1, double x2) __attribute__((always_inline)) {
+                    if (r < npair) {
+                        put_value(Tb + 2 * (2 * r), b.gen + 1u, x1 * 0x1p-22);
+                        put_value(Tb + 2 * (2 * r + 1), b.gen + 1u, x2 * GRID);
+                    } else {
+                        const int k = r - npair;
+                        if constexpr (CK == 2) {
+                            if (k == 0) { put_value(Tb + 2 * nv0, b.gen + 1u, x1); put_value(Tb + 2 * (nv0 + 1), b.gen + 1u, x2); }
+                            else put_value(Tb + 2 * (nv0 + 1 + k), b.gen + 1u, (double)((long long)x1 | ((long long)x2 << 26)));
+                        } else put_value(Tb + 2 * (nv0 + k), b.gen + 1u, (double)((long long)x1 | ((long long)x2 << 24)));
+                    }
+                };
+                if (rows == 1) {
+                    double x1 = 0.0, x2 = 0.0;
+                    if (tid < W) {
+                        Spin sp;
+                        sp.start(spin_limit);
+                        const unsigned long long* gp = Pb + 2 * ((size_t)wg * a.Wpad + tid);
+                        while (!get_packed(gp, tag24, x1, x2)) {
+                            if (sp.expired(abort_word)) { bad = true; x1 = 0.0; x2 = 0.0; break; }
+                        }
+                    }
+                    const double r2 = reduce2(x1, x2);        // lanes 0-31: sum of x1 over the wavefront, lanes 32-63: of x2 (exact values: any order)
+                    if (lane == 0) s_red[wave] = r2;
+                    if (lane == 32) s_red[4 + wave] = r2;
+                    lds_barrier();
+                    if (tid == 0) emit_row(wg, s_red[0] + s_red[1] + s_red[2] + s_red[3], s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+                    lds_barrier();
+                } else {
+                    // several rows (few workgroups, or a long tail behind a crossed stop): every thread takes granule pairs t, t + 256, ...
+                    // of the rows x W this workgroup needs and adds each to its row's LDS accumulators (ds_add_f64: exact values, any order)
+                    double* s_rows = reinterpret_cast<double*>(smem + L_TOT);       // free until wavefront 0 polls the totals
+                    for (int r = tid; r < 2 * rows; r += SW_TPB) s_rows[r] = 0.0;
+                    lds_barrier();
+                    const int total = rows * W;
+                    for (int g = tid; g < total; g += SW_TPB) {
+                        const int r = g / W, i = g - r * W;
+                        Spin sp;
+                        sp.start(spin_limit);
+                        double x1 = 0.0, x2 = 0.0;
+                        const unsigned long long* gp = Pb + 2 * ((size_t)(wg + r * W) * a.Wpad + i);
+                        while (!get_packed(gp, tag24, x1, x2)) {
+                            if (sp.expired(abort_word)) { bad = true; x1 = 0.0; x2 = 0.0; break; }
+                        }
+                        __hip_atomic_fetch_add(&s_rows[2 * r], x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(&s_rows[2 * r + 1], x2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    lds_barrier();
+                    for (int r = tid; r < rows; r += SW_TPB) emit_row(wg + r * W, s_rows[2 * r], s_rows[2 * r + 1]);
+                    lds_barrier();
+                }
+                return bad;
+            }
+#endif
             if (!a.reduce4 && rows <= 2) {
                 if (wave != 0) return false;
                 for (int r = 0; r < rows; r++) {              // (uniform)
@@ -2729,7 +2905,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         return bad;
     };
 
-    Batch cur{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0};
+    Batch cur{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0, 0};
     const int tdelay = LONGB ? a.totals_delay : a.totals_delay2;    // wavefront 0: s_sleep units (64 clocks) before the first look at the totals (see there)
     LaneIn li_cur0{0, 0, 0.0, 0.0, 1.0}, li_cur1{0, 0, 0.0, 0.0, 1.0};
     bool bad = false;
