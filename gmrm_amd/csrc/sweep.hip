@@ -2806,7 +2806,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 }
                 return bad;
             }
-#endif
+#else
             if (!a.reduce4 && rows <= 2) {
                 if (wave != 0) return false;
                 for (int r = 0; r < rows; r++) {              // (uniform)
@@ -2901,6 +2901,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 for (int r = tid; r < rows; r += SW_TPB) put_value(Tb + 2 * (wg + r * W), b.gen + 1u, s_rows[r]);
                 lds_barrier();
             }
+#endif
         }
         return bad;
     };
