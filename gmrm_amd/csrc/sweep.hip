@@ -2992,7 +2992,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 // look that fails is not free: 245 workgroups looking at the same 4 KB 3.7 times per round slow the round trips of
                 // everybody (measured: a wait of 1.2 us before the first look, -1.7 % on 500k x 1M; two looks in flight, +4 %:
                 // profiles/r04_ab_totals_delay.txt, r04_ab_poll_two_looks.txt).  The host picks the wait from the grid's size.
-                for (int i = 0; i < tdelay; i++) __builtin_amdgcn_s_sleep(1);
+                // (a short batch has few rows, few reducers and its totals early: 770 -> 758 ms for the first sweep of a chain without the wait)
+                const int tdl = cur.nv >= 128 ? tdelay : (cur.nv >= 64 ? tdelay / 2 : 0);
+                for (int i = 0; i < tdl; i++) __builtin_amdgcn_s_sleep(1);
                 int nlooks = 0;
                 if constexpr (CONT) okw = poll_totals_x(cur.nv, Tb, (cur.gen + 1u) & 0xFFFFFFu, smem, abort_word, spin_limit);
                 else okw = poll_totals<true>(cur.nb, cur.nv, 0ull, 0ull, Tb, cur.gen + 1u, smem, t0, t1, abort_word, spin_limit, nlooks);

@@ -331,12 +331,16 @@ def test_long_chain_stays_bit_exact(gpu):
                                  dict(GMRM_NB_FACTOR16="8"), dict(GMRM_NB_FACTOR16="256", GMRM_SWEEP_R="2", GMRM_NO_CROSS="1"),
                                  dict(GMRM_LONG_CROSS="2", GMRM_LONG_CROSS_FRAC16="1", GMRM_NB_FACTOR16="256", GMRM_SWEEP_R="2"),
                                  dict(GMRM_LONG_CROSS="2", GMRM_LONG_CROSS_FRAC16="4", GMRM_NB_FACTOR16="64", GMRM_SWEEP_R="4"),
-                                 dict(GMRM_LONG_CROSS="2", GMRM_LONG_CROSS_FRAC16="1", GMRM_NB_FACTOR16="256")])
+                                 dict(GMRM_LONG_CROSS="2", GMRM_LONG_CROSS_FRAC16="1", GMRM_NB_FACTOR16="256"),
+                                 dict(GMRM_NO_DIRECT_PUBLISH="1", GMRM_NO_TILE_TRIM="1", GMRM_TOTALS_DELAY="0", GMRM_TOTALS_DELAY2="40"),
+                                 dict(GMRM_NB_FACTOR16="64", GMRM_BATCH_CAP="100", GMRM_TOTALS_DELAY="100")])
 def test_kernel_geometries_and_schedules_give_the_same_chain(gpu, monkeypatch, env):
     """The results may not depend on how the kernel is laid out or scheduled: bytes per thread
     R = 1 / 2 / 4 (slice width, tile window, register-home tiles at R = 2 / 4, batch cap), who takes the reduce role,
     larger and smaller batches (up to the 240-marker cap of the long-batch kernel, kept on it by GMRM_NO_CROSS); the long-batch
-    kernel that crosses stops (GMRM_LONG_CROSS=2: in dense models as well) with crossings wherever a marker lies behind the stop.
+    kernel that crosses stops (GMRM_LONG_CROSS=2: in dense models as well) with crossings wherever a marker lies behind the stop;
+    the round-4 schedule knobs at their non-default ends (rows published through LDS, untrimmed batches, waits before the polls,
+    a batch cap).
     Cases: no missing genotypes (2-value exchange layout, packed partial sums) and 5 % missing (4-value layout)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
