@@ -61,6 +61,9 @@
 
 namespace gm {
 
+#ifndef GM_ROWS_BY_LANE
+#define GM_ROWS_BY_LANE 1         // 0: the long-batch kernel stores a tile's rows one after the other (A/B builds)
+#endif
 #ifndef GM_PACK_ROWS
 #define GM_PACK_ROWS 1            // 0: the kernels other than the long-batch ones exchange one value per granule pair (rounds 1-3; A/B builds)
 #endif
@@ -944,6 +947,14 @@ __device__ __noinline__ void sample_batch(int nb, int mpos0, int bmax_, int nbf1
                                           int ns, int ps0, int ps1) {
     Totals tq0 = tot0, tq1 = tot1;
     sample_batch_body<K, CK, LONGB>(nb, mpos0, bmax_, nbf16, G, smem, tab, lin0, lin1, tq0, tq1, Draws{p0, p1}, sigmae, inv2sige, nm1, out, writer, l_cass, ns, ps0, ps1);
+}
+
+// lanes 0..3 of every 16-lane row take `src` from the lane SHR places below them where that lane is in the row; the others keep
+// `old` (DPP row_shr, bank 0, bound_ctrl off): after SHR = 1, 2, 3 in this order lane r of a row holds what lane 0 held in call r
+template <int SHR> __device__ __forceinline__ long long row_take64(long long old, long long src) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x110 + SHR, 0xf, 0x1, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(old >> 32), (int)(src >> 32), 0x110 + SHR, 0xf, 0x1, false);
+    return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
 // ---- the walk of a long batch on four wavefronts ("parallel passes", round 4) -------------------------------
@@ -2392,6 +2403,29 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             };
 #pragma unroll
             for (int q = 0; q < NTL; q++) {
+#if GM_ROWS_BY_LANE
+                if constexpr (LONGB && !CONT && TF) {
+                    // The four rows (markers 4 kg .. 4 kg + 3) of a lane group leave in ONE store instruction: their sums are formed one
+                    // after the other (the quad sums need every lane), then row r's two parts move to lane n = r (row_take64) and lanes
+                    // 0..3 pack, address and store together -- instead of four times with one lane of sixteen at work.
+                    long long a1 = 0, a2 = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int xr = acc0[q][r] + (acc1[q][r] >> 2) + (acc2[q][r] >> 4);
+                        const long long sx = planes_sum(n == 7 ? 0 : xr);
+                        const long long s2 = shl4(sx);
+                        if (r == 0) { a1 = sx; a2 = s2; }
+                        if (r == 1) { a1 = row_take64<1>(a1, sx); a2 = row_take64<1>(a2, s2); }
+                        if (r == 2) { a1 = row_take64<2>(a1, sx); a2 = row_take64<2>(a2, s2); }
+                        if (r == 3) { a1 = row_take64<3>(a1, sx); a2 = row_take64<3>(a2, s2); }
+                    }
+                    const int mr = 16 * tq[q] + 4 * kg + n - p0;                     // lane n < 4: batch position of row n
+                    if (n < 4 && (unsigned)mr < (unsigned)nb)
+                        put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)mr * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu, a1, a2);
+                } else
+#endif
+                // (the short-batch kernels' direct publish stores row by row: gathering the rows in lanes as above measured slower
+                //  there -- c5 +1.5 %, c6 +0.4 % -- four more 64-bit values live across the loop in kernels that spill already)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int m = 16 * tq[q] + 4 * kg + r - p0;                      // batch position of this row
