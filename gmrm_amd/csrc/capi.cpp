@@ -484,6 +484,7 @@ int gmrm_marker_stats(gmrm_ctx* c, int t) {
         size_t clean = 0;
         for (uint8_t v : nm) clean += v ? 1 : 0;
         tr.miss_mode = clean == nm.size() ? 0 : (clean == 0 ? 2 : 1);
+        tr.n_dirty = (long long)(nm.size() - clean);
     }
     tr.have_stats = true;
     return GMRM_OK;
@@ -795,6 +796,14 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     // is the same either way, bit for bit.  GMRM_NO_CROSS=1 / GMRM_FORCE_CROSS=1: A/B knobs.
     a.cross = 0;
     a.long_cross = 0;
+    // Some markers with missing genotypes (mode 1): when they are few (at most one in 30: a batch of 240 then seldom holds more than the
+    // eight whose Z terms the kernel gathers) and the model is sparse, the sweep runs on the long-batch kernel too (sweep.hip: every
+    // tile on the one-MFMA-set pass, the dirty markers' Z terms gathered from the digit planes).  GMRM_NO_LONG_MIXED=1: A/B knob.
+    a.long_mixed = 0;
+    if (a.miss_mode == 1 && !std::getenv("GMRM_NO_LONG_MIXED")) {
+        const bool dense = (double)tr.in_model >= c->cross_density * (double)c->M;
+        if (!dense && tr.n_dirty * 30 <= (long long)c->M) a.long_mixed = 1;
+    }
     if ((a.miss_mode == 0 || a.miss_mode == 2) && !std::getenv("GMRM_NO_CROSS")) {      // (the mixed layout, mode 1, has no such kernel)
         const bool dense = (double)tr.in_model >= c->cross_density * (double)c->M;      // (as of the last completed sweep)
         if (dense || std::getenv("GMRM_FORCE_CROSS")) a.cross = c->cross_frac16;

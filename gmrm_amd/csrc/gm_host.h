@@ -23,6 +23,7 @@ struct Trait {
     double* acum = nullptr;         // Phenotype::acum [M]
     int nonas = 0;
     bool have_trait = false, have_stats = false, in_flight = false, empty = false;
+    long long n_dirty = 0;          // markers of the block with a missing genotype among the phenotyped individuals (gmrm_marker_stats)
     int part_next = 0;              // a sweep in parts (gmrm_sweep_in.first / count): the position the next part starts at (0: a new sweep)
     bool part_last = true;          // the part in flight ends the sweep: its finish makes the new effects current
     bool holds_devlock = false;     // this sweep holds the per-device advisory lock against other processes (capi.cpp)

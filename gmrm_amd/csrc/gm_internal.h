@@ -65,6 +65,7 @@ struct SweepArgs {
     unsigned nl_magic;
     int cross;                     // > 0: the walk may cross a marker whose effect was non-zero when at least cross/16 of the batch
                                    // lies behind it (a crossing costs about half a round; 0: never)
+    int long_mixed;                // the per-marker layout (some markers with missing genotypes) on the long-batch kernel: sparse model, few such markers
     int long_cross;                // with cross > 0 in the layout without missing genotypes: the long-batch kernel that crosses stops
                                    // (sparse models) instead of the short-batch one (dense models)
 };

@@ -957,6 +957,37 @@ template <int SHR> __device__ __forceinline__ long long row_take64(long long old
     return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+// ... and for the long batches (four groups of 64 positions)
+struct DirtyMasks { unsigned long long m0, m1, m2, m3; };
+__device__ __forceinline__ bool dirty_at4(const DirtyMasks& d, int p) {
+    const unsigned long long m = p < 64 ? d.m0 : (p < 128 ? d.m1 : (p < 192 ? d.m2 : d.m3));
+    return ((m >> (p & 63)) & 1ull) != 0ull;
+}
+__device__ __forceinline__ int dirty_rank4(const DirtyMasks& d, int p) {
+    const unsigned long long below = (1ull << (p & 63)) - 1ull;
+    int r = 0;
+    r += p >= 64 ? __popcll(d.m0) : __popcll(d.m0 & below);
+    if (p >= 64) r += p >= 128 ? __popcll(d.m1) : __popcll(d.m1 & below);
+    if (p >= 128) r += p >= 192 ? __popcll(d.m2) : __popcll(d.m2 & below);
+    if (p >= 192) r += __popcll(d.m3 & below);
+    return r;
+}
+// batch position of the u-th dirty marker (uniform; u below the number of dirty markers)
+__device__ __forceinline__ int dirty_pos4(DirtyMasks d, int u) {
+    int pos = 0;
+    for (int i = 0; i <= u; i++) {
+        if (d.m0) { pos = __ffsll((long long)d.m0) - 1; d.m0 &= d.m0 - 1ull; }
+        else if (d.m1) { pos = 64 + __ffsll((long long)d.m1) - 1; d.m1 &= d.m1 - 1ull; }
+        else if (d.m2) { pos = 128 + __ffsll((long long)d.m2) - 1; d.m2 &= d.m2 - 1ull; }
+        else { pos = 192 + __ffsll((long long)d.m3) - 1; d.m3 &= d.m3 - 1ull; }
+    }
+    return pos;
+}
+__device__ __forceinline__ DirtyMasks dirty_trim4(DirtyMasks d, int nb) {          // keep the flags of positions below nb
+    auto keep = [&](unsigned long long m, int lo) { return nb >= lo + 64 ? m : (nb > lo ? (m & ((1ull << (nb - lo)) - 1ull)) : 0ull); };
+    return DirtyMasks{keep(d.m0, 0), keep(d.m1, 64), keep(d.m2, 128), keep(d.m3, 192)};
+}
+
 // ---- the walk of a long batch on four wavefronts ("parallel passes", round 4) -------------------------------
 // In the two-value layout with nothing to cross (the stationary sweeps of a block without missing genotypes) a batch holds up to
 // 240 markers and the walk is the largest item of a round: four passes of 64 markers, one after the other, on one wavefront
@@ -1119,8 +1150,8 @@ __device__ __forceinline__ void pass_close_no_stop(const PassEval& ev, int nb, i
 }
 // One wavefront's part of a long batch's walk, start to end: evaluate my pass, meet the others, commit.  Called by all four
 // wavefronts (the barrier inside is the workgroup's).  mine: this wavefront has positions and its totals; okw: the totals arrived.
-template <int K, class TP>
-__device__ __forceinline__ void long_batch_body(int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const double* s_tot, int* s_res,
+template <int K, bool MIXED, class TP>
+__device__ __forceinline__ void long_batch_body(int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const double* s_tot, const DirtyMasks& dk, int* s_res,
                                                 double sigmae, double inv2sige, double nm1, int G, char* smem, TP tab,
                                                 const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16) {
     const int lane = threadIdx.x & 63;
@@ -1133,7 +1164,9 @@ __device__ __forceinline__ void long_batch_body(int nb, int wave, bool mine, boo
     if (mine) {                                                          // (uniform per wavefront)
         const int base = 64 * wave;
         const int pc = base + lane < nb ? base + lane : 0;
-        const double dpa = s_tot[pc], dpb = s_tot[nb];                   // one total per marker and the common one (packed exchange)
+        // one total per marker and the common one (packed exchange); a marker with missing genotypes has a row of its own for sum b eps
+        const bool dirty = MIXED && (dk.m0 | dk.m1 | dk.m2 | dk.m3) != 0ull && dirty_at4(dk, pc);
+        const double dpa = s_tot[pc], dpb = s_tot[dirty ? nb + 1 + dirty_rank4(dk, pc) : nb];
         ev = pass_eval<K>(nb, base, 0, cursor_w, in, dpa, dpb, ctl[C_EMA] >= ctl[C_SCRMIN], inv2sige, nm1, G, smem, tab, tb, prob, acum_v, muk, logl);
     }
     if (lane == 0) s_res[wave] = (mine && ev.s < ev.nbp) ? ev.s : -1;
@@ -1144,25 +1177,25 @@ __device__ __forceinline__ void long_batch_body(int nb, int wave, bool mine, boo
         pass_commit<K>(ev, wave == wstop, nb, 64 * wave, in, tb, prob, acum_v, muk, logl, sigmae, out, writer, l_cass, bmax_, nbf16, smem);
     if (okw && wstop == 4 && wave == ((nb - 1) >> 6)) pass_close_no_stop(ev, nb, bmax_, nbf16, smem);
 }
-template <int K, class TP>
-__device__ __noinline__ void long_batch_k(int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const double* s_tot, int* s_res,
+template <int K, bool MIXED, class TP>
+__device__ __noinline__ void long_batch_k(int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const double* s_tot, const DirtyMasks& dk, int* s_res,
                                           double sigmae, double inv2sige, double nm1, int G, char* smem, TP tab,
                                           const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16) {
-    long_batch_body<K>(nb, wave, mine, okw, cursor_w, in, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16);
+    long_batch_body<K, MIXED>(nb, wave, mine, okw, cursor_w, in, s_tot, dk, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16);
 }
 // K = 4 (the reference's example mixtures) is inlined into the kernel; other K share out-of-line copies.
-template <class TP>
-__device__ __forceinline__ void long_batch_other_k(int K, int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const double* s_tot, int* s_res,
+template <bool MIXED, class TP>
+__device__ __forceinline__ void long_batch_other_k(int K, int nb, int wave, bool mine, bool okw, int cursor_w, const LaneIn& in, const double* s_tot, const DirtyMasks& dk, int* s_res,
                                                    double sigmae, double inv2sige, double nm1, int G, char* smem, TP tab,
                                                    const SampleOut out, bool writer, int l_cass, int bmax_, int nbf16) {
     const LaneIn lc = in;                                                // (by address: hand over a copy, the kernel's own stays in registers)
     switch (K) {
-        case 2: long_batch_k<2>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
-        case 3: long_batch_k<3>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
-        case 5: long_batch_k<5>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
-        case 6: long_batch_k<6>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
-        case 7: long_batch_k<7>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
-        default: long_batch_k<8>(nb, wave, mine, okw, cursor_w, lc, s_tot, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+        case 2: long_batch_k<2, MIXED>(nb, wave, mine, okw, cursor_w, lc, s_tot, dk, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+        case 3: long_batch_k<3, MIXED>(nb, wave, mine, okw, cursor_w, lc, s_tot, dk, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+        case 5: long_batch_k<5, MIXED>(nb, wave, mine, okw, cursor_w, lc, s_tot, dk, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+        case 6: long_batch_k<6, MIXED>(nb, wave, mine, okw, cursor_w, lc, s_tot, dk, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+        case 7: long_batch_k<7, MIXED>(nb, wave, mine, okw, cursor_w, lc, s_tot, dk, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
+        default: long_batch_k<8, MIXED>(nb, wave, mine, okw, cursor_w, lc, s_tot, dk, s_res, sigmae, inv2sige, nm1, G, smem, tab, out, writer, l_cass, bmax_, nbf16); break;
     }
 }
 
@@ -1613,7 +1646,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
 template <int R, int MODE, bool CONT, bool LONG>
 __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     static_assert(!CONT || MODE == 0 || MODE == 2, "continuation: the fast layout and the all-dirty layout");
-    static_assert(!LONG || MODE == 0, "long batches: the layout without missing genotypes");
+    static_assert(!LONG || MODE == 0 || (MODE == 1 && !CONT), "long batches: no missing genotypes, or a few markers with some (their Z terms gathered: sparse_z)");
     static_assert(LONG || CONT || MODE != 0, "the fast layout without crossings is the long-batch kernel");
     constexpr int CK = !CONT ? 0 : (MODE == 0 ? 1 : 2);   // 1: no marker has a missing genotype (among the phenotyped), 2: every marker may
     constexpr bool FAST = MODE == 0;
@@ -2017,7 +2050,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
     // ---- the marker loop ---------------------------------------------------------------------------------
     // Generation g uses tag g+1 and buffer g&1; a buffer is rewritten only after every
     // workgroup has sampled the generation that used it.
-    struct Batch { int p0, nb, nv; unsigned gen; bool planned; unsigned long long dm0, dm1; int ns, ps0, ps1; int nr; };   // nv: totals the walk waits for; nr: rows of partial sums the reducers sum   // planned: ends at a marker known to stop the walk; dm: dirty positions;
+    struct Batch { int p0, nb, nv; unsigned gen; bool planned; unsigned long long dm0, dm1; int ns, ps0, ps1; int nr; unsigned long long dm2, dm3; };   // nv: totals the walk waits for; nr: rows of partial sums the reducers sum   // planned: ends at a marker known to stop the walk; dm: dirty positions;
                                                                                                                 // ns, ps: the markers with a non-zero effect the walk may cross (batch positions)
     unsigned gen_next = 0;
     long long n_upd = 0, n_batch = 0, n_planned = 0, n_stale = 0, n_fastb = 0, n_cross = 0, n_short = 0;
@@ -2039,8 +2072,9 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         const double rb0 = mr_beta[sl0], rb1 = mr_beta[sl1];
         double rb2 = 0.0, rb3 = 0.0;
         if (NPASS > 2) { rb2 = mr_beta[(p0 + lane + 128) & (META_POS - 1)]; rb3 = mr_beta[(p0 + lane + 192) & (META_POS - 1)]; }
-        unsigned char rn0 = 1, rn1 = 1;
+        unsigned char rn0 = 1, rn1 = 1, rn2 = 1, rn3 = 1;
         if (MODE == 1) { rn0 = mr_nm[sl0]; rn1 = mr_nm[sl1]; }
+        if (MODE == 1 && NPASS > 2) { rn2 = mr_nm[(p0 + lane + 128) & (META_POS - 1)]; rn3 = mr_nm[(p0 + lane + 192) & (META_POS - 1)]; }
         LaneIn r0i{0, 0, 0.0, 0.0, 1.0}, r1i{0, 0, 0.0, 0.0, 1.0};
         if constexpr (LONGB) {                        // parallel passes: wavefront w samples positions 64 w .. 64 w + 63
             const int slw = (p0 + lane + 64 * wave) & (META_POS - 1);
@@ -2051,12 +2085,21 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
         // Dirty markers (a missing genotype among the phenotyped individuals) exchange two more values each: the batch
         // is cut where the slots run out.  (Every wavefront reads the same LDS bytes: uniform.)
-        unsigned long long dm0 = 0ull, dm1 = 0ull;
+        unsigned long long dm0 = 0ull, dm1 = 0ull, dm2 = 0ull, dm3 = 0ull;
+        // The long-batch kernel for blocks with a FEW markers that have missing genotypes: every tile runs the one-MFMA-set pass and
+        // the Z terms of a batch's dirty markers are gathered from the digit planes (sparse_z below).  At most ZCAP of them per
+        // batch (staging slots for the register-home ones): the batch is cut before the next.
+        constexpr int ZCAP = SPARSE_ZMAX < SW_VMAX * 8 / GE::SB ? SPARSE_ZMAX : SW_VMAX * 8 / GE::SB;
+        if constexpr (LONGB && MODE == 1) {
+            dm0 = __ballot(lane < b.nb && rn0 == 0); dm1 = __ballot(lane + 64 < b.nb && rn1 == 0);
+            dm2 = __ballot(lane + 128 < b.nb && rn2 == 0); dm3 = __ballot(lane + 192 < b.nb && rn3 == 0);
+            if (__popcll(dm0) + __popcll(dm1) + __popcll(dm2) + __popcll(dm3) > ZCAP) b.nb = dirty_pos4(DirtyMasks{dm0, dm1, dm2, dm3}, ZCAP);   // (uniform; >= 1: ZCAP >= 1)
+        }
         if (MODE == 2) {                              // every marker dirty: 4 slots each, the r-th dirty marker is position r
             if (b.nb > (SW_VMAX - 2) / 4) b.nb = (SW_VMAX - 2) / 4;
             dm0 = ~0ull; dm1 = ~0ull;
         }
-        if (MODE == 1) {
+        if (MODE == 1 && !LONGB) {
             const bool q0 = lane < b.nb && rn0 == 0;
             const bool q1 = lane + 64 < b.nb && rn1 == 0;
             dm0 = __ballot(q0); dm1 = __ballot(q1);
@@ -2148,15 +2191,20 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
             dm0 = nb >= 64 ? dm0 : (dm0 & ((1ull << nb) - 1ull));
             dm1 = nb >= 128 ? dm1 : (nb > 64 ? (dm1 & ((1ull << (nb - 64)) - 1ull)) : 0ull);
         }
-        b.dm0 = dm0; b.dm1 = dm1;
-        const int nd = __popcll(dm0) + __popcll(dm1);
-        const bool all_dirty = MODE == 2 || nd == nb; // then the r-th dirty marker is batch position r
+        if constexpr (LONGB && MODE == 1) {
+            const DirtyMasks t = dirty_trim4(DirtyMasks{dm0, dm1, dm2, dm3}, nb);
+            dm0 = t.m0; dm1 = t.m1; dm2 = t.m2; dm3 = t.m3;
+        }
+        b.dm0 = dm0; b.dm1 = dm1; b.dm2 = dm2; b.dm3 = dm3;
+        const DirtyMasks dmk{dm0, dm1, dm2, dm3};
+        const int nd = __popcll(dm0) + __popcll(dm1) + __popcll(dm2) + __popcll(dm3);
+        const bool all_dirty = MODE == 2 || (!LONGB && nd == nb); // then the r-th dirty marker is batch position r
         // A few dirty markers among clean ones: every tile runs the one-MFMA-set pass (X = sum c d) and the
         // missing-genotype term Z of each dirty marker is gathered from the digit planes, one wavefront per
         // marker (sparse_z below), instead of a second MFMA set over every tile that holds such a marker.  Only where every
         // dirty marker of the batch lives in an LDS tile (a register tile's slice is not addressable lane by lane).
-        bool sparse_z = MODE == 1 && !all_dirty && nd > 0 && nd <= SPARSE_ZMAX;      // uniform
-        if constexpr (MODE == 1 && RPER != 0) {
+        bool sparse_z = MODE == 1 && !all_dirty && nd > 0 && nd <= SPARSE_ZMAX;      // uniform (the long-batch kernel: always, nd <= ZCAP by the cut above)
+        if constexpr (MODE == 1 && RPER != 0 && !LONGB) {
             if (sparse_z) {
                 unsigned long long r0 = dm0, r1 = dm1;
                 while (r0 | r1) {
@@ -2177,6 +2225,11 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
         max_nb = nb > max_nb ? nb : max_nb;
         PA(1);
+        if constexpr (LONGB && MODE == 1) {
+            if (nd > 0) {                             // (uniform) the long-batch kernel: the slices of register-home dirty markers are staged by their owners first
+                if (stage_slices(nd, [&](int u) __attribute__((always_inline)) { return p0 + dirty_pos4(dmk, u); })) lds_barrier();
+            }
+        }
         if constexpr (MODE == 1) {
             if (sparse_z) {
                 // Z of a dirty marker = sum over its missing genotypes of the residual's two exact parts as grid
@@ -2187,16 +2240,13 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                 // 4 dword + byte, the order of operand B).  No f64 work, nothing that depends on who owns whom.
                 // Done BEFORE the tile passes: its two dependent LDS round trips cost ~100 cycles each now and
                 // several hundred once the four wavefronts stream operands for the MFMAs.
-                unsigned long long r0 = dm0, r1 = dm1;
                 int r = 0;
 #pragma unroll 1
-                while (r0 | r1) {
-                    int m;
-                    if (r0) { m = __ffsll((long long)r0) - 1; r0 &= r0 - 1ull; }
-                    else    { m = 64 + __ffsll((long long)r1) - 1; r1 &= r1 - 1ull; }
+                for (; r < nd; ) {
+                    const int m = dirty_pos4(dmk, r);
                     if ((r & 3) == wave) {
                         const int pm = p0 + m;
-                        const SliceAt sa = slice_at(pm, 0);                              // (an LDS tile: checked above)
+                        const SliceAt sa = slice_at(pm, r);                              // (an LDS tile, or -- the long-batch kernel -- staging slot r)
                         const char* slice = sa.base;
                         const int swz = sa.swz;
                         long long z1 = 0, z2 = 0;
@@ -2233,6 +2283,17 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                         if (lane == 0) { s_zsp[2 * r] = t1; s_zsp[2 * r + 1] = t2; }     // read at the publish, after the barrier
                     }
                     r++;
+                }
+                if constexpr (LONGB) {
+                    // the long-batch kernel publishes from the tile passes: the Z terms have to be there first; the dirty markers' own
+                    // rows (sum b d = sum d - Z: this slice's sums of q minus Z) leave right here
+                    lds_barrier();
+                    if (tid < nd) {
+                        const long long q1 = (long long)((s_wsq[0] + s_wsq[2] + s_wsq[4] + s_wsq[6]) * 0x1p22);
+                        const long long q2 = (long long)((s_wsq[1] + s_wsq[3] + s_wsq[5] + s_wsq[7]) * GRID_INV);
+                        put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)(nb + 1 + tid) * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu,
+                                   q1 - s_zsp[2 * tid], q2 - s_zsp[2 * tid + 1]);
+                    }
                 }
             }
         }
@@ -2420,6 +2481,14 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                         if (r == 3) { a1 = row_take64<3>(a1, sx); a2 = row_take64<3>(a2, s2); }
                     }
                     const int mr = 16 * tq[q] + 4 * kg + n - p0;                     // lane n < 4: batch position of row n
+                    if constexpr (MODE == 1) {
+                        if (nd > 0) {                          // (uniform) a dirty marker's row: sum a d = X - 3 Z (c = 3 where the genotype is missing)
+                            if (n < 4 && (unsigned)mr < (unsigned)nb && dirty_at4(dmk, mr)) {
+                                const int rk = dirty_rank4(dmk, mr);
+                                a1 -= 3 * s_zsp[2 * rk]; a2 -= 3 * s_zsp[2 * rk + 1];
+                            }
+                        }
+                    }
                     if (n < 4 && (unsigned)mr < (unsigned)nb)
                         put_packed(Pg + 2 * ((size_t)(b.gen & 1u) * SW_VMAX * a.Wpad + (size_t)mr * a.Wpad + wg), (b.gen + 1u) & 0xFFFFFFu, a1, a2);
                 } else
@@ -2527,7 +2596,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         };
         using ICSS = std::integral_constant<int, SS>;
         auto one_pass = [&](auto kr_tag, auto nld_tag, int tR, int tL0, int tL1, bool dirty) __attribute__((always_inline))  {
-            if constexpr (MODE == 0) tile_pass(kr_tag, nld_tag, std::true_type{}, ICSS{}, tR, tL0, tL1, 0);
+            if constexpr (MODE == 0 || (LONGB && MODE == 1)) tile_pass(kr_tag, nld_tag, std::true_type{}, ICSS{}, tR, tL0, tL1, 0);   // (the long-batch kernel gathers the Z terms: sparse_z)
             else if constexpr (MODE == 2) tile_pass(kr_tag, nld_tag, std::false_type{}, ICSS{}, tR, tL0, tL1, 0);
             else { if (dirty) tile_pass(kr_tag, nld_tag, std::false_type{}, ICSS{}, tR, tL0, tL1, 0); else tile_pass(kr_tag, nld_tag, std::true_type{}, ICSS{}, tR, tL0, tL1, 0); }
         };
@@ -2582,7 +2651,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         }
         PA(2);
         if constexpr (LONGB) {                        // (published from the tile passes: nothing to collect)
-            b.nv = nb + 1 + ((CONT && ns > 0) ? nb - 1 - ps0 : 0);   // behind a crossed stop: one more row per marker (the packed G)
+            b.nv = nb + 1 + ((CONT && ns > 0) ? nb - 1 - ps0 : 0) + (MODE == 1 ? nd : 0);   // behind a crossed stop: one more row per marker (the packed G); a row per dirty marker
             b.nr = b.nv;
             PA(3);
             PA(4);
@@ -2940,7 +3009,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         return bad;
     };
 
-    Batch cur{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0, 0};
+    Batch cur{0, 0, 0, 0u, false, 0ull, 0ull, 0, 0, 0, 0, 0ull, 0ull};
     const int tdelay = LONGB ? a.totals_delay : a.totals_delay2;    // wavefront 0: s_sleep units (64 clocks) before the first look at the totals (see there)
     LaneIn li_cur0{0, 0, 0.0, 0.0, 1.0}, li_cur1{0, 0, 0.0, 0.0, 1.0};
     bool bad = false;
@@ -3054,11 +3123,13 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
                                               so, wg == 0, a.lds_cass, bcap_rt, a.nb_factor16, cur.ns, cur.ps0, cur.ps1);
                 else long_cont_other_k(K, cur.nb, wave, okw && nbw > 0, okw, cursor_w, li_cur0, s_toth, s_totl, s_res, a.sigmae, a.inv2sige, a.nm1, G, smem, (TabLds)s_tab,
                                        so, wg == 0, a.lds_cass, bcap_rt, a.nb_factor16, cur.ns, cur.ps0, cur.ps1);
-            } else
-            if (K == 4) long_batch_body<4>(cur.nb, wave, okw && nbw > 0, okw, cursor_w, li_cur0, s_tot, s_res, a.sigmae, a.inv2sige, a.nm1, G, smem, (TabLds)s_tab,
+            } else {
+            const DirtyMasks dkm{cur.dm0, cur.dm1, cur.dm2, cur.dm3};
+            if (K == 4) long_batch_body<4, MODE == 1>(cur.nb, wave, okw && nbw > 0, okw, cursor_w, li_cur0, s_tot, dkm, s_res, a.sigmae, a.inv2sige, a.nm1, G, smem, (TabLds)s_tab,
                                            so, wg == 0, a.lds_cass, bcap_rt, a.nb_factor16);
-            else long_batch_other_k(K, cur.nb, wave, okw && nbw > 0, okw, cursor_w, li_cur0, s_tot, s_res, a.sigmae, a.inv2sige, a.nm1, G, smem, (TabLds)s_tab,
+            else long_batch_other_k<MODE == 1>(K, cur.nb, wave, okw && nbw > 0, okw, cursor_w, li_cur0, s_tot, dkm, s_res, a.sigmae, a.inv2sige, a.nm1, G, smem, (TabLds)s_tab,
                                     so, wg == 0, a.lds_cass, bcap_rt, a.nb_factor16);
+            }
         } else
         if (wave == 0) {
             const SampleOut so{a.acum, a.betas_out, a.comp};
@@ -3110,7 +3181,7 @@ __global__ __launch_bounds__(SW_TPB, 1) void k_sweep(const SweepArgs a) {
         const bool upd = nupd != 0;
         n_planned += ctl[C_PLN];
         n_cross += ctl[C_SUPD];
-        n_fastb += (cur.dm0 | cur.dm1) == 0ull ? 1 : 0;
+        n_fastb += (cur.dm0 | cur.dm1 | cur.dm2 | cur.dm3) == 0ull ? 1 : 0;
         n_stale += cur.nb - n_done;                   // dots computed behind the stop: thrown away
         if (upd) {
             n_upd += nupd;
@@ -3217,7 +3288,7 @@ template <int R> static hipError_t launch_R(const SweepArgs& a, hipStream_t st, 
             if (a.cross > 0) return a.long_cross ? launch_RF<R, 0, true, true>(a, st, grid) : launch_RF<R, 0, true, false>(a, st, grid);
             return launch_RF<R, 0, false, true>(a, st, grid);
         case 2: return a.cross > 0 ? launch_RF<R, 2, true, false>(a, st, grid) : launch_RF<R, 2, false, false>(a, st, grid);
-        default: return launch_RF<R, 1, false, false>(a, st, grid);
+        default: return a.long_mixed ? launch_RF<R, 1, false, true>(a, st, grid) : launch_RF<R, 1, false, false>(a, st, grid);
     }
 }
 

@@ -411,6 +411,34 @@ def test_exchange_layout_is_chosen_per_batch(gpu, one_in, calls):
     ctx.close()
 
 
+@pytest.mark.parametrize("N,M,env", [(30_000, 6_000, dict(GMRM_SWEEP_R="2", GMRM_NB_FACTOR16="256")), (30_000, 6_000, dict()),
+                                     (250_000, 2_400, dict(GMRM_SWEEP_R="2", GMRM_NB_FACTOR16="256")),
+                                     (30_000, 6_000, dict(GMRM_SWEEP_R="4", GMRM_NB_FACTOR16="64"))])
+def test_few_markers_with_missing_genotypes_run_on_the_long_batch_kernel(gpu, monkeypatch, N, M, env):
+    """Round 4: a block in which FEW markers have missing genotypes (one in 60 here; real arrays always have some) and a sparse
+    model no longer falls back to the short-batch kernel: k_sweep<R, 1, false, true> -- every tile on the one-MFMA-set pass, the Z
+    terms of a batch's dirty markers gathered from the digit planes (slices of register-home markers staged by their owners), the
+    dirty markers' rows of sum b eps published beside the packed marker rows, at most eight dirty markers per batch.  Bit-exact
+    against the oracle, with and without register-home tiles, few and many workgroups."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case = cases.Case("lmixed", N, M, 1, 4, 1, 0.0, 60, 4242, 7 if N < 100_000 else 5, 10)
+    inp = cases.make_inputs(case)
+    rng = np.random.default_rng(9)
+    dirty = rng.choice(case.M, size=case.M // 60, replace=False)
+    for m in dirty:
+        who = rng.choice(case.N, size=int(rng.integers(1, 60)), replace=False)
+        for i in who:
+            b, k = divmod(int(i), 4)
+            inp["bed"][m, b] = (int(inp["bed"][m, b]) & (0xFF ^ (3 << (2 * k)))) | (1 << (2 * k))     # code 01 = missing
+    got = cases.run_gpu(case, inp)
+    want = cases.run_oracle(case, inp, canon=True)
+    cases.assert_same_history(got, want, exact=True)
+    h = got[0]
+    print("updates per sweep", h["nupd"], "rounds", h["nbatch"])
+    assert h["nbatch"][-1] < M // 25                                   # long batches: the long-batch kernel ran
+
+
 def test_per_step_calls_and_the_sweep_kernel_are_one_chain(gpu):
     """gmrm_sampler_begin_steps / _step / _end_steps (the reference's per-marker loop, bayes.cpp:376-492, with the
     residual update applied by the caller, bayes.cpp:681-706) interleaved with kernel sweeps on ONE shard: iteration 1

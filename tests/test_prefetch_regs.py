@@ -11,8 +11,8 @@ ROOT = Path(__file__).resolve().parent.parent
 def test_prefetch_registers_are_untouched_until_the_wait():
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "check_prefetch_regs.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("ok  ") == 36           # (AGPR tiles + staged LDS reads) x R in {1,2,4} x {no missing genotypes: long batches, short batches that cross stops,
-                                                   #  long batches that cross stops; all markers (with / without the continuation); some markers}
+    assert r.stdout.count("ok  ") == 42           # (AGPR tiles + staged LDS reads) x R in {1,2,4} x {no missing genotypes: long batches, short batches that cross stops,
+                                                   #  long batches that cross stops; all markers (with / without the continuation); some markers (short and long batches)}
 
 
 def _checker():
