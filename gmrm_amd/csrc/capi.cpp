@@ -810,7 +810,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
         // Sparse models in the layout without missing genotypes (the stationary sweeps): the long-batch kernel that crosses stops --
         // batches of up to 240 markers, the walk on four wavefronts, the exact sums exchanged (sweep.hip, long_cont_body).  Exact
         // and tested, but NOT the default: on 500k x 1M it takes 12 % fewer rounds and 10 % more time (a crossing costs about as
-        // much as the round it saves while the tile window holds 22 tiles: profiles/r04_ab_long_batch_crossing.txt).
+        // much as the round it saves while the tile window holds 20 tiles: profiles/r04_ab_long_batch_crossing.txt).
         // GMRM_LONG_CROSS=1: in sparse models; 2: in dense models as well.
         if (a.miss_mode == 0 && c->long_cross > 0 && (!dense || c->long_cross > 1)) { a.cross = c->long_cross_frac16; a.long_cross = 1; }
     }
