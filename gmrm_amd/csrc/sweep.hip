@@ -1165,8 +1165,13 @@ __device__ __forceinline__ void long_batch_body(int nb, int wave, bool mine, boo
         const int base = 64 * wave;
         const int pc = base + lane < nb ? base + lane : 0;
         // one total per marker and the common one (packed exchange); a marker with missing genotypes has a row of its own for sum b eps
-        const bool dirty = MIXED && (dk.m0 | dk.m1 | dk.m2 | dk.m3) != 0ull && dirty_at4(dk, pc);
-        const double dpa = s_tot[pc], dpb = s_tot[dirty ? nb + 1 + dirty_rank4(dk, pc) : nb];
+        const double dpa = s_tot[pc];
+        double dpb = s_tot[nb];
+        if constexpr (MIXED) {
+            if ((dk.m0 | dk.m1 | dk.m2 | dk.m3) != 0ull) {          // (uniform: most batches of a block with few dirty markers have none or a few)
+                if (dirty_at4(dk, pc)) dpb = s_tot[nb + 1 + dirty_rank4(dk, pc)];
+            }
+        }
         ev = pass_eval<K>(nb, base, 0, cursor_w, in, dpa, dpb, ctl[C_EMA] >= ctl[C_SCRMIN], inv2sige, nm1, G, smem, tab, tb, prob, acum_v, muk, logl);
     }
     if (lane == 0) s_res[wave] = (mine && ev.s < ev.nbp) ? ev.s : -1;
@@ -3275,8 +3280,10 @@ template <int R, int MODE, bool CONT, bool LONG> static hipError_t launch_RF(con
 }
 #ifdef GM_ONE_KERNEL
 // experiments on code generation (tools/one_kernel.sh): only one k_sweep is instantiated -- not a product build
-#ifdef GM_ONE_KERNEL_CONT
+#if defined(GM_ONE_KERNEL_CONT)
 hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) { return launch_RF<2, 0, true, true>(a, st, grid); }
+#elif defined(GM_ONE_KERNEL_MIXED)
+hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) { return launch_RF<2, 1, false, true>(a, st, grid); }
 #else
 hipError_t launch_sweep(const SweepArgs& a, int R, hipStream_t st, int grid) { return launch_RF<2, 0, false, true>(a, st, grid); }
 #endif
