@@ -785,7 +785,7 @@ int gmrm_sweep_launch(gmrm_ctx* c, int t, const gmrm_sweep_in* in) {
     a.screen_min_run16 = c->screen_min_run16;
     a.miss_mode = tr.miss_mode;
     if (std::getenv("GMRM_FORCE_MIXED")) a.miss_mode = 1;     // diagnostic: run any block through the per-marker-layout kernel
-    a.reduce4 = std::getenv("GMRM_REDUCE_W0") ? 0 : 1;      // A/B knob: in the kernels without long batches all four wavefronts reduce (measured: c2 22.7 / 23.6 ms, c6 148 / 154, c5 equal)
+    a.reduce4 = std::getenv("GMRM_REDUCE_W0") ? 0 : 1;      // (only read by builds with -DGM_PACK_ROWS=0: the short-batch kernels' reduce role on wavefront 0 alone; measured c2 22.7 / 23.6 ms, c6 148 / 154, c5 equal)
     // The walk may cross markers whose effect was non-zero: when no marker of the block has a missing genotype among the
     // phenotyped individuals (mode 0: mave * nonas is then the integer sum of a marker's genotype values; flags and means
     // come from gmrm_marker_stats -- values set through gmrm_set_marker_stats leave miss_mode at 2), or when every marker

@@ -327,7 +327,7 @@ def test_long_chain_stays_bit_exact(gpu):
 
 
 @pytest.mark.parametrize("env", [dict(GMRM_SWEEP_R="2"), dict(GMRM_SWEEP_R="4"),
-                                 dict(GMRM_REDUCE_W0="1"), dict(GMRM_REDUCE_W0="1", GMRM_NB_FACTOR16="64", GMRM_SWEEP_R="2"),
+                                 dict(GMRM_NB_FACTOR16="40", GMRM_SWEEP_R="1"), dict(GMRM_NB_FACTOR16="64", GMRM_SWEEP_R="2"),
                                  dict(GMRM_NB_FACTOR16="8"), dict(GMRM_NB_FACTOR16="256", GMRM_SWEEP_R="2", GMRM_NO_CROSS="1"),
                                  dict(GMRM_LONG_CROSS="2", GMRM_LONG_CROSS_FRAC16="1", GMRM_NB_FACTOR16="256", GMRM_SWEEP_R="2"),
                                  dict(GMRM_LONG_CROSS="2", GMRM_LONG_CROSS_FRAC16="4", GMRM_NB_FACTOR16="64", GMRM_SWEEP_R="4"),
@@ -336,7 +336,7 @@ def test_long_chain_stays_bit_exact(gpu):
                                  dict(GMRM_NB_FACTOR16="64", GMRM_BATCH_CAP="100", GMRM_TOTALS_DELAY="100")])
 def test_kernel_geometries_and_schedules_give_the_same_chain(gpu, monkeypatch, env):
     """The results may not depend on how the kernel is laid out or scheduled: bytes per thread
-    R = 1 / 2 / 4 (slice width, tile window, register-home tiles at R = 2 / 4, batch cap), who takes the reduce role,
+    R = 1 / 2 / 4 (slice width, tile window, register-home tiles at R = 2 / 4, batch cap),
     larger and smaller batches (up to the 240-marker cap of the long-batch kernel, kept on it by GMRM_NO_CROSS); the long-batch
     kernel that crosses stops (GMRM_LONG_CROSS=2: in dense models as well) with crossings wherever a marker lies behind the stop;
     the round-4 schedule knobs at their non-default ends (rows published through LDS, untrimmed batches, waits before the polls,
